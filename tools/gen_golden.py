@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors from the REFERENCE (runs in the build container only).
+
+Imports hkbharath/MARL-MASS from /root/reference under the stand-ins in tools/refshim/
+(gym / pygame stubs, numpy+pandas compat, and a cvxopt stand-in whose `solvers.qp` is the exact
+KKT closed form -- cvxopt 1.2.7 is not installable here, see tools/refshim/cvxopt/__init__.py).
+Everything else that runs is the reference's own arithmetic.  The outputs are DATA only
+(tests/golden/*.npz); no reference source is copied.
+
+    python tools/gen_golden.py            # regenerate every fixture
+
+Fixture families
+  units.npz        pure-function tables (lane argmin, steering control, rect intersection, ...)
+  reset.npz        reference reset() results for given seeds / vehicle counts
+  ep_*.npz         episode tapes: initial state, action tape, per-sub-step vehicle state,
+                   per-step obs / rewards / dones / info, and (shield runs) every QP (G, h, x)
+"""
+import os
+import sys
+import json
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.dont_write_bytecode = True
+sys.path[:0] = [os.path.join(HERE, "refshim"), "/root/reference"]
+
+import numpy as np  # noqa: E402
+import _refcompat  # noqa: E402,F401
+import gym  # noqa: E402
+import highway_env  # noqa: E402,F401
+import cvxopt  # noqa: E402
+from highway_env import utils as hutils  # noqa: E402
+from highway_env.road.road import Road  # noqa: E402
+from highway_env.vehicle.safety.cbf import CBFType  # noqa: E402
+from highway_env.vehicle.controller import MDPVehicle  # noqa: E402
+from highway_env.vehicle.safe_controller import MDPLCVehicle  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+LANE_ID = {("a", "b", 0): 0, ("b", "c", 0): 1, ("b", "c", 1): 2,
+           ("c", "d", 0): 3, ("j", "k", 0): 4, ("k", "b", 0): 5}
+LANE_IX = {v: k for k, v in LANE_ID.items()}
+HL = {None: -1, "LANE_LEFT": 0, "IDLE": 1, "LANE_RIGHT": 2, "FASTER": 3, "SLOWER": 4}
+
+_SUBSTEP_LOG = None
+_orig_road_step = Road.step
+
+
+def _veh_snapshot(v):
+    """One row of per-vehicle state as the reference holds it after a sub-step."""
+    is_lc = isinstance(v, MDPLCVehicle)
+    sa = getattr(v, "safe_action", None) or v.action
+    fg = getattr(v, "fg_params", None)
+    f = [v.position[0], v.position[1], v.heading, v.speed, v.target_speed,
+         float(v.action["steering"]), float(v.action["acceleration"]),
+         float(sa["steering"]), float(sa["acceleration"]),
+         float(fg["g"]["vx"]) if fg else np.nan]
+    i = [LANE_ID[tuple(v.lane_index)], LANE_ID[tuple(v.target_lane_index)], int(v.speed_index),
+         int(bool(v.crashed)), HL[getattr(v, "hl_action", None)],
+         int(bool(getattr(v, "collaborate_adj", False))) if is_lc else 0,
+         int(bool(getattr(v, "is_lc_safe", False))) if is_lc else 0,
+         int(bool(getattr(v, "is_collaborating", False))) if is_lc else 0]
+    return f, i
+
+
+def _road_step_logged(self, dt):
+    _orig_road_step(self, dt)
+    if _SUBSTEP_LOG is not None:
+        rows = [_veh_snapshot(v) for v in self.vehicles]
+        _SUBSTEP_LOG.append((np.array([r[0] for r in rows], dtype=np.float64),
+                             np.array([r[1] for r in rows], dtype=np.int32)))
+
+
+Road.step = _road_step_logged
+
+
+def make_env(env_id, shield, n_cav, headway_time, eta):
+    """Mirror of how run_mappo.py:137-171 configures an env (values from the cited .ini files)."""
+    CBFType.GAMMA_B = eta
+    CBFType.TAU = headway_time
+    env = gym.make(env_id)
+    env.config["simulation_frequency"] = 15
+    env.config["duration"] = 20
+    env.config["policy_frequency"] = 5
+    env.config["COLLISION_REWARD"] = 200
+    env.config["HIGH_SPEED_REWARD"] = 1
+    env.config["HEADWAY_COST"] = 4
+    env.config["HEADWAY_TIME"] = headway_time
+    env.config["MERGING_LANE_COST"] = 4
+    env.config["traffic_density"] = 1
+    env.config["action_masking"] = False
+    env.config["safety_guarantee"] = shield
+    env.config["lateral_control"] = "steer"
+    env.config["mixed_traffic"] = False
+    env.config["traffic_type"] = "cav"
+    env.config["agent_reward"] = "default"
+    # BASELINE configs fix the vehicle count (N CAVs, 0 HDVs); the reference draws it at random.
+    env._num_vehicles = lambda num_CAV=0: (n_cav, 0)
+    return env
+
+
+def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta, p=None,
+                max_steps=100, scripted=None):
+    global _SUBSTEP_LOG
+    env = make_env(env_id, shield, n_cav, headway_time, eta)
+    obs0, mask0 = env.reset(is_training=False, testing_seeds=seed)
+    n = len(env.controlled_vehicles)
+    assert n == n_cav and len(env.road.vehicles) == n_cav
+    init_f, init_i = zip(*[_veh_snapshot(v) for v in env.road.vehicles])
+    rng = np.random.RandomState(tape_seed)
+    p = p or [0.1, 0.6, 0.1, 0.1, 0.1]
+    cvxopt.solvers.log = []
+    sub_f, sub_i, sub_count = [], [], []
+    rec = {k: [] for k in ("actions", "obs", "reward", "done", "agents_rewards", "regional_rewards",
+                           "agents_dones", "average_speed", "traffic_speed", "min_headway",
+                           "merge_percent", "action_mask", "qp_count")}
+    done = False
+    t = 0
+    while not done and t < max_steps:
+        if scripted is not None:
+            a = tuple(int(x) for x in scripted[min(t, len(scripted) - 1)])
+        else:
+            a = tuple(int(x) for x in rng.choice(5, size=n, p=p))
+        _SUBSTEP_LOG = []
+        nqp0 = len(cvxopt.solvers.log)
+        obs, reward, done, info = env.step(a)
+        sub_count.append(len(_SUBSTEP_LOG))
+        for f, i in _SUBSTEP_LOG:
+            sub_f.append(f)
+            sub_i.append(i)
+        _SUBSTEP_LOG = None
+        rec["actions"].append(a)
+        rec["obs"].append(np.asarray(obs, dtype=np.float64))
+        rec["reward"].append(float(reward))
+        rec["done"].append(bool(done))
+        rec["agents_rewards"].append(np.array(info["agents_rewards"], dtype=np.float64))
+        rec["regional_rewards"].append(np.array(info["regional_rewards"], dtype=np.float64))
+        rec["agents_dones"].append(np.array(info["agents_dones"], dtype=bool))
+        rec["average_speed"].append(float(info["average_speed"]))
+        rec["traffic_speed"].append(float(info["traffic_speed"]))
+        rec["min_headway"].append(float(info["min_headway"]))
+        rec["merge_percent"].append(float(info.get("merge_percent", np.nan)))
+        rec["action_mask"].append(np.asarray(info["action_mask"], dtype=np.uint8))
+        rec["qp_count"].append(len(cvxopt.solvers.log) - nqp0)
+        t += 1
+    qps = cvxopt.solvers.log
+    cvxopt.solvers.log = None
+    qp_rows = np.array([g.shape[0] for g, _, _ in qps], dtype=np.int32)
+    qp_G = np.zeros((len(qps), 4, 3))
+    qp_h = np.full((len(qps), 4), np.nan)
+    qp_x = np.zeros((len(qps), 3))
+    for k, (g, h, x) in enumerate(qps):
+        qp_G[k, :g.shape[0]] = g
+        qp_h[k, :h.shape[0]] = h
+        qp_x[k] = x
+    meta = dict(env_id=env_id, shield=shield, n=n_cav, seed=seed, tape_seed=tape_seed,
+                headway_time=headway_time, eta=eta, n_merge=int(env.n_merge),
+                n_s=int(env.n_s), crashed=bool(env.is_crashed()), steps=t,
+                qp_solver="exact-KKT closed form (cvxopt 1.2.7 unavailable)")
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        meta=json.dumps(meta),
+        init_f=np.array(init_f), init_i=np.array(init_i, dtype=np.int32),
+        obs0=np.asarray(obs0, dtype=np.float64), mask0=np.asarray(mask0, dtype=np.uint8),
+        sub_f=np.array(sub_f), sub_i=np.array(sub_i, dtype=np.int32),
+        sub_count=np.array(sub_count, dtype=np.int32),
+        actions=np.array(rec["actions"], dtype=np.int32), obs=np.array(rec["obs"]),
+        reward=np.array(rec["reward"]), done=np.array(rec["done"]),
+        agents_rewards=np.array(rec["agents_rewards"]),
+        regional_rewards=np.array(rec["regional_rewards"]),
+        agents_dones=np.array(rec["agents_dones"]),
+        average_speed=np.array(rec["average_speed"]), traffic_speed=np.array(rec["traffic_speed"]),
+        min_headway=np.array(rec["min_headway"]), merge_percent=np.array(rec["merge_percent"]),
+        action_mask=np.array(rec["action_mask"]), qp_count=np.array(rec["qp_count"], dtype=np.int32),
+        qp_rows=qp_rows, qp_G=qp_G, qp_h=qp_h, qp_x=qp_x)
+    print("%-40s steps=%3d crashed=%d qps=%d" % (name, t, meta["crashed"], len(qps)))
+    return meta
+
+
+def gen_units():
+    env = make_env("merge-multi-agent-v1", "none", 4, 1.2, 0.0)
+    env.reset(is_training=False, testing_seeds=0)
+    net = env.road.network
+    rs = np.random.RandomState(7)
+    out = {}
+    # lane constants as the reference builds them (merge_env_v1.py:222-248)
+    lanes = [net.get_lane(LANE_IX[i]) for i in range(6)]
+    out["lane_start"] = np.array([l.start for l in lanes], dtype=np.float64)
+    out["lane_end"] = np.array([l.end for l in lanes], dtype=np.float64)
+    out["lane_length"] = np.array([l.length for l in lanes], dtype=np.float64)
+    out["lane_forbidden"] = np.array([l.forbidden for l in lanes], dtype=np.uint8)
+    sl = lanes[5]
+    out["sine"] = np.array([sl.amplitude, sl.pulsation, sl.phase], dtype=np.float64)
+    out["obstacle"] = np.array(env.road.objects[0].position, dtype=np.float64)
+    # closest lane + next lane + per-lane frames on random poses (road.py:51-109, lane.py)
+    n = 4000
+    px = rs.uniform(-20, 520, n)
+    py = rs.uniform(-3, 14, n)
+    ph = rs.uniform(-0.6, 0.6, n)
+    # plus poses that hug the lane centre lines (typical states)
+    px[: n // 2] = rs.uniform(0, 500, n // 2)
+    ysel = rs.randint(0, 4, n // 2)
+    py[: n // 2] = np.where(ysel == 0, 0.0, np.where(ysel == 1, 4.0, np.where(ysel == 2, 10.5, 0)))
+    onramp = ysel == 3
+    py[: n // 2][onramp] = 7.25 + 3.25 * np.cos(np.pi * (px[: n // 2][onramp] - 220) / 100)
+    py[: n // 2] += rs.normal(0, 0.3, n // 2)
+    ph[: n // 2] = rs.normal(0, 0.05, n // 2)
+    closest = np.zeros(n, dtype=np.int32)
+    nxt = np.zeros((n, 6), dtype=np.int32)
+    local = np.zeros((n, 6, 2))
+    lane_heading = np.zeros((n, 6))
+    dist_h = np.zeros((n, 6))
+    onlane = np.zeros((n, 6), dtype=np.uint8)
+    reach = np.zeros((n, 6), dtype=np.uint8)
+    after = np.zeros((n, 6), dtype=np.uint8)
+    for k in range(n):
+        pos = np.array([px[k], py[k]])
+        closest[k] = LANE_ID[net.get_closest_lane_index(pos, ph[k])]
+        for li in range(6):
+            l = lanes[li]
+            s, r = l.local_coordinates(pos)
+            local[k, li] = (s, r)
+            lane_heading[k, li] = l.heading_at(s)
+            dist_h[k, li] = l.distance_with_heading(pos, ph[k])
+            onlane[k, li] = bool(l.on_lane(pos))
+            reach[k, li] = bool(l.is_reachable_from(pos))
+            after[k, li] = bool(l.after_end(pos))
+            nxt[k, li] = LANE_ID[net.next_lane(LANE_IX[li], position=pos)]
+    out.update(pose_x=px, pose_y=py, pose_h=ph, closest=closest, next_lane=nxt, local=local,
+               lane_heading=lane_heading, dist_heading=dist_h, on_lane=onlane, reachable=reach,
+               after_end=after)
+    # steering_control / speed_control / get_corner (controller.py:146-197,257-267)
+    veh = env.controlled_vehicles[0]
+    m = 3000
+    sx = rs.uniform(0, 500, m)
+    sy = rs.uniform(-2, 12.5, m)
+    sh = rs.normal(0, 0.15, m)
+    sv = rs.uniform(0, 35, m)
+    sv[:50] = rs.uniform(-0.02, 0.02, 50)  # not_zero branch
+    stl = rs.randint(0, 6, m)
+    steer = np.zeros(m)
+    corner = np.zeros((m, 2, 2))
+    for k in range(m):
+        veh.position = np.array([sx[k], sy[k]])
+        veh.heading = sh[k]
+        veh.speed = sv[k]
+        steer[k] = veh.steering_control(LANE_IX[int(stl[k])])
+        corner[k, 0] = veh.get_corner("L")
+        corner[k, 1] = veh.get_corner("R")
+    out.update(sc_x=sx, sc_y=sy, sc_h=sh, sc_v=sv, sc_lane=stl.astype(np.int32), sc_steer=steer,
+               corner=corner)
+    # speed_to_index incl. exact .5 boundaries (controller.py:327-337); wrap_to_pi; not_zero
+    sp = np.concatenate([np.linspace(0, 45, 181), [12.5, 17.5, 22.5, 27.5, 7.5, 32.5]])
+    out["sti_speed"] = sp
+    out["sti_index"] = np.array([veh.speed_to_index(s) for s in sp], dtype=np.int32)
+    wa = np.concatenate([rs.uniform(-20, 20, 500), [np.pi, -np.pi, 0.0, 3 * np.pi, -3 * np.pi]])
+    out["wrap_in"] = wa
+    out["wrap_out"] = np.array([hutils.wrap_to_pi(a) for a in wa])
+    # rotated rectangle intersection (utils.py:90-121), vehicle vs vehicle and vehicle vs obstacle
+    q = 6000
+    rect = np.zeros((q, 6))
+    hit = np.zeros(q, dtype=np.uint8)
+    hit_obs = np.zeros(q, dtype=np.uint8)
+    for k in range(q):
+        dx, dy = rs.uniform(-6, 6), rs.uniform(-3.5, 3.5)
+        a1, a2 = rs.normal(0, 0.3), rs.normal(0, 0.3)
+        cx, cy = rs.uniform(0, 400), rs.uniform(0, 10)
+        rect[k] = (cx, cy, a1, cx + dx, cy + dy, a2)
+        hit[k] = hutils.rotated_rectangles_intersect(
+            (np.array([cx, cy]), 4.5, 1.8, a1), (np.array([cx + dx, cy + dy]), 4.5, 1.8, a2))
+        hit_obs[k] = hutils.rotated_rectangles_intersect(
+            (np.array([cx, cy]), 4.5, 1.8, a1), (np.array([cx + dx, cy + dy]), 1.8, 1.8, 0.0))
+    out.update(rect=rect, rect_hit=hit, rect_hit_obstacle=hit_obs)
+    np.savez_compressed(os.path.join(OUT, "units.npz"), **out)
+    print("units.npz: %d poses, %d steering cases, %d rect pairs (%d/%d hits)"
+          % (n, m, q, hit.sum(), hit_obs.sum()))
+
+
+def gen_reset():
+    """reset() of the reference for a list of (seed, n_cav): initial state + obs (abstract.py:176-209)."""
+    rows = []
+    for env_id in ("merge-multi-agent-v0", "merge-multi-agent-v1"):
+        for n_cav in (2, 3, 4, 5, 8, 11):
+            for seed in (0, 25, 50, 1000, 1001):
+                env = make_env(env_id, "none", n_cav, 1.2, 0.0)
+                obs, mask = env.reset(is_training=False, testing_seeds=seed)
+                f, i = zip(*[_veh_snapshot(v) for v in env.road.vehicles])
+                rows.append(dict(env=env_id, n=n_cav, seed=seed, n_merge=int(env.n_merge),
+                                 f=np.array(f)[:, :5].tolist(), i=np.array(i)[:, :3].tolist(),
+                                 obs=np.asarray(obs).tolist()))
+    # also the reference's own count draw (merge_env_v1.py:180-211) for traffic_density 1..3
+    counts = []
+    for td in (1, 2, 3):
+        for seed in (0, 25, 50, 75):
+            env = gym.make("merge-multi-agent-v1")
+            env.config["traffic_density"] = td
+            env.config["traffic_type"] = "cav"
+            env.reset(is_training=False, testing_seeds=seed)
+            f, i = zip(*[_veh_snapshot(v) for v in env.road.vehicles])
+            counts.append(dict(td=td, seed=seed, n=len(env.controlled_vehicles),
+                               n_merge=int(env.n_merge), f=np.array(f)[:, :5].tolist()))
+    with open(os.path.join(OUT, "reset.json"), "w") as fh:
+        json.dump(dict(fixed=rows, drawn=counts), fh)
+    print("reset.json: %d fixed-count resets, %d drawn-count resets" % (len(rows), len(counts)))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    gen_units()
+    gen_reset()
+    metas = []
+    v0, v1 = "merge-multi-agent-v0", "merge-multi-agent-v1"
+    # (1) unshielded, reference arithmetic end to end (configs_marl-cav-unsafe.ini: tau 1.2)
+    for seed in (0, 25, 50):
+        metas.append(run_episode("ep_v0_none_N4_s%d" % seed, v0, "none", 4, seed, 123 + seed, 1.2, 0.0))
+    metas.append(run_episode("ep_v0_none_N8_s0", v0, "none", 8, 0, 7, 1.2, 0.0))
+    metas.append(run_episode("ep_v1_none_N4_s0", v1, "none", 4, 0, 123, 1.2, 0.0))
+    metas.append(run_episode("ep_v1_none_N8_s25", v1, "none", 8, 25, 11, 0.5, 0.0))
+    # idle-only tapes run the full 100 steps without a shield (long-horizon drift check)
+    metas.append(run_episode("ep_v0_idle_N4_s0", v0, "none", 4, 0, 0, 1.2, 0.0,
+                             scripted=[(1, 1, 1, 1)]))
+    # (2) shields; eta / tau from marl_cav-heading-t_headway-cbf-{avs_cint,cav}.ini
+    for seed in (0, 25, 50):
+        metas.append(run_episode("ep_v1_hss_N4_s%d" % seed, v1, "cbf-avs_cint", 4, seed, 123 + seed,
+                                 0.5, 0.03125))
+        metas.append(run_episode("ep_v1_mass_N4_s%d" % seed, v1, "cbf-cav", 4, seed, 123 + seed,
+                                 0.5, 0.03125))
+    for seed in (0, 25):
+        metas.append(run_episode("ep_v1_mass_N8_s%d" % seed, v1, "cbf-cav", 8, seed, 200 + seed,
+                                 0.5, 0.03125))
+    metas.append(run_episode("ep_v1_hss_N8_s0", v1, "cbf-avs_cint", 8, 0, 200, 0.5, 0.03125))
+    # lane-change heavy tapes exercise the LC veto / constrain_adj / collaborate paths
+    lc = [0.3, 0.2, 0.3, 0.1, 0.1]
+    metas.append(run_episode("ep_v1_mass_N8_lc_s75", v1, "cbf-cav", 8, 75, 5, 0.5, 0.03125, p=lc))
+    metas.append(run_episode("ep_v1_hss_N4_lc_s75", v1, "cbf-avs_cint", 4, 75, 5, 0.5, 0.03125, p=lc))
+    metas.append(run_episode("ep_v1_mass_N11_s100", v1, "cbf-cav", 11, 100, 9, 0.5, 0.03125))
+    # a different eta / tau pair (eta_binary_search.sh:3-8 sweeps eta)
+    metas.append(run_episode("ep_v1_mass_N4_eta05_s125", v1, "cbf-cav", 4, 125, 3, 1.2, 0.5))
+    with open(os.path.join(OUT, "index.json"), "w") as fh:
+        json.dump(metas, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
