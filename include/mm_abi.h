@@ -1,0 +1,248 @@
+/*
+ * mm_abi.h -- C ABI of the MI355X-native batched on-ramp-merge environment + CBF shield.
+ *
+ * This is the drop-in boundary for the ONE hot path of hkbharath/MARL-MASS: `env.reset` /
+ * `env.step` of the merge envs and the HSS / MASS CBF action filter.  The reference has no FFI
+ * layer (it is 100 % Python); each entry point below names the Python interface it replaces.
+ * All paths are relative to the reference repository root.
+ *
+ * Two libraries export exactly these symbols:
+ *   marl-mass_amd/csrc  -> libmm_hip.so     pointers marked DEV are device (HBM) pointers
+ *   oracle/             -> libmm_oracle.so  CPU twin, same signatures, DEV pointers are host
+ *                                           pointers and `stream` is ignored (test infra only)
+ *
+ * Memory model: the CALLER owns every buffer (PyTorch tensors in practice).  The library never
+ * allocates in reset/step; the handle is a small host struct that borrows the state buffer.
+ * Re-entrant per handle, no global mutable state (the reference keeps class-level globals
+ * CBFType.GAMMA_B / CBFType.TAU, cbf.py:18,24 -- here they are MMConfig fields).
+ *
+ * State layout ("(env,agent)-major struct of arrays"): agent index i = e * N + a, a in [0, N).
+ * The state buffer is  [MM_F_COUNT planes of double[E*N]] [MM_B_COUNT planes of uint8[E*N]]
+ * [MM_E_COUNT planes of int32[E]] [1 plane of uint64[E] (per-env seed)], each block 256-B aligned;
+ * byte offsets come from mm_state_layout().
+ */
+#ifndef MM_ABI_H
+#define MM_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_ABI_VERSION 1
+#define MM_MAX_AGENTS 16 /* vehicles per env (reference draws 2..11, merge_env_v1.py:180-211) */
+#define MM_N_ACTIONS 5   /* DiscreteMetaAction.ACTIONS_ALL, envs/common/action.py:141-147 */
+#define MM_OBS_ROWS 5    /* KinematicObservation vehicles_count, envs/common/observation.py:132 */
+
+/* env_kind: which registered env the handle mirrors (merge_env_v1.py:681-689) */
+#define MM_ENV_V0 0 /* merge-multi-agent-v0: MDPVehicle, Kinematics obs (5 features, n_s = 25) */
+#define MM_ENV_V1 1 /* merge-multi-agent-v1: MDPLCVehicle, KinematicLC obs (6 features, n_s = 30) */
+
+/* shield: config["safety_guarantee"] after `.split("-")[1]` (safe_controller.py:241) */
+#define MM_SHIELD_NONE 0
+#define MM_SHIELD_HSS 1  /* "cbf-av" | "cbf-avs" | "cbf-avs_cint" | "cbf-hss"  -> safe_action_hss  */
+#define MM_SHIELD_MASS 2 /* "cbf-cav" | "cbf-mass"                              -> safe_action_mass */
+
+/* lane ids = insertion order of the road network (merge_env_v1.py:231-245, road.py:60-64) */
+#define MM_LANE_AB0 0
+#define MM_LANE_BC0 1
+#define MM_LANE_BC1 2
+#define MM_LANE_CD0 3
+#define MM_LANE_JK0 4
+#define MM_LANE_KB0 5
+
+/* per-agent float64 planes */
+enum {
+  MM_F_X = 0,        /* Vehicle.position[0]                      kinematics.py:41  */
+  MM_F_Y,            /* Vehicle.position[1]                                         */
+  MM_F_HEADING,      /* Vehicle.heading                                              */
+  MM_F_SPEED,        /* Vehicle.speed                                                */
+  MM_F_TARGET_SPEED, /* ControlledVehicle.target_speed           controller.py:47  */
+  MM_F_SAFE_STEER,   /* MDPLCVehicle.safe_action["steering"]     safe_controller.py:122 */
+  MM_F_SAFE_ACC,     /* MDPLCVehicle.safe_action["acceleration"]                     */
+  MM_F_G_VX,         /* MDPLCVehicle.fg_params["g"]["vx"]        safe_controller.py:167 */
+  MM_F_H1_X,         /* state_hist[-1]: x, heading, vx, speed    safe_controller.py:187-201 */
+  MM_F_H1_HEADING,
+  MM_F_H1_VX,
+  MM_F_H1_SPEED,
+  MM_F_H2_X,         /* state_hist[-2] (read by the shield, decentral_layer.py:126,202) */
+  MM_F_H2_HEADING,
+  MM_F_H2_VX,
+  MM_F_H2_SPEED,
+  MM_F_COUNT
+};
+
+/* per-agent uint8 planes */
+enum {
+  MM_B_LANE = 0,    /* Vehicle.lane_index as lane id            kinematics.py:44 */
+  MM_B_TARGET_LANE, /* ControlledVehicle.target_lane_index      controller.py:46 */
+  MM_B_SPEED_INDEX, /* MDPVehicle.speed_index                   controller.py:290 */
+  MM_B_CRASHED,     /* Vehicle.crashed                          kinematics.py:48 */
+  MM_B_HL_ACTION,   /* MDPLCVehicle.hl_action (0..4), 255=None  safe_controller.py:48,65 */
+  MM_B_FLAGS,       /* bit0 collaborate_adj, bit1 is_lc_safe, bit2 is_collaborating (:50,60,61) */
+  MM_B_HIST_LEN,    /* min(len(state_hist), 2); >=1 also means fg_params is set (:232-239) */
+  MM_B_KIND,        /* 0 absent, 1 controlled CAV (HDVs: reserved 2) */
+  MM_B_COUNT
+};
+#define MM_FLAG_COLLABORATE_ADJ 1u
+#define MM_FLAG_IS_LC_SAFE 2u
+#define MM_FLAG_IS_COLLABORATING 4u
+#define MM_HL_NONE 255u
+
+/* per-env int32 planes */
+enum {
+  MM_E_STEPS = 0, /* AbstractEnv.steps   abstract.py:67,457 */
+  MM_E_TIME,      /* AbstractEnv.time    abstract.py:66,521 */
+  MM_E_N_MERGE,   /* MergeEnv.n_merge    merge_env_v1.py:262,364 */
+  MM_E_EPISODE,   /* episodes started on this env slot (device RNG counter) */
+  MM_E_COUNT
+};
+
+typedef struct MMStateLayout {
+  uint64_t f64_offset; /* double[MM_F_COUNT][E*N] */
+  uint64_t u8_offset;  /* uint8 [MM_B_COUNT][E*N] */
+  uint64_t env_offset; /* int32 [MM_E_COUNT][E]   */
+  uint64_t seed_offset;/* uint64[E]               */
+  uint64_t total_bytes;
+} MMStateLayout;
+
+/*
+ * Host-side configuration.  Mirrors the env.config keys run_mappo.py:145-171 writes plus the two
+ * CBF class globals (run_mappo.py:138-139).  Defaults are merge_env_v1.py:33-57.
+ */
+typedef struct MMConfig {
+  int32_t abi_version;          /* MM_ABI_VERSION */
+  int32_t env_kind;             /* MM_ENV_V0 | MM_ENV_V1 */
+  int32_t shield;               /* MM_SHIELD_* ; ignored (none) for MM_ENV_V0 */
+  int32_t simulation_frequency; /* 15 */
+  int32_t policy_frequency;     /* 5  */
+  int32_t duration;             /* 20 -> T = duration * policy_frequency = 100 */
+  int32_t action_masking;       /* config["action_masking"] (abstract.py:200-207,474-481) */
+  int32_t auto_reset;           /* 1: step() re-spawns finished envs with the device RNG */
+  int32_t obs_f64;              /* 0: obs written as float32, 1: float64 (reference dtype) */
+  int32_t reserved0;
+  double collision_reward;      /* COLLISION_REWARD 200 */
+  double high_speed_reward;     /* HIGH_SPEED_REWARD 1  */
+  double headway_cost;          /* HEADWAY_COST 4       */
+  double headway_time;          /* HEADWAY_TIME 1.2 (reward, merge_env_v1.py:82) */
+  double merging_lane_cost;     /* MERGING_LANE_COST 4  */
+  double reward_speed_lo;       /* reward_speed_range[0] 10 */
+  double reward_speed_hi;       /* reward_speed_range[1] 30 */
+  double cbf_eta;               /* CBFType.GAMMA_B (cbf_eta in the .ini) */
+  double cbf_tau;               /* CBFType.TAU     (HEADWAY_TIME in the .ini) */
+  uint64_t seed;                /* base seed of the device RNG; env e uses seed + e unless seeds given */
+} MMConfig;
+
+/*
+ * Outputs of one step.  Any pointer may be NULL (that output is skipped).  DEV pointers.
+ * Mirrors the (obs, reward, done, info) tuple of MergeEnv.step (merge_env_v1.py:126-166) and
+ * AbstractEnv.step (abstract.py:443-510), batched over E envs.
+ */
+typedef struct MMStepOut {
+  void *obs;                /* [E][N][5*F] float32|float64, F = 5 (v0) | 6 (v1)           */
+  double *reward;           /* [E]      _reward: mean of agent rewards (:59-62)            */
+  uint8_t *done;            /* [E]      _is_terminal (:168-172)                            */
+  double *agents_rewards;   /* [E][N]   info["agents_rewards"]   (:139-142)                */
+  double *regional_rewards; /* [E][N]   info["regional_rewards"] (:144-145)                */
+  uint8_t *agents_dones;    /* [E][N]   info["agents_dones"]     (:131)                    */
+  double *agents_info;      /* [E][N][3] info["agents_info"] = x, y, speed (:132-136)      */
+  uint8_t *crashed;         /* [E][N]   vehicle.crashed at the end of the step             */
+  double *average_speed;    /* [E]      info["average_speed"] (abstract.py:483-485)        */
+  double *traffic_speed;    /* [E]      info["traffic_speed"] (:147-151)                   */
+  double *min_headway;      /* [E]      info["min_headway"]   (:152, :373-386)             */
+  double *merge_percent;    /* [E]      info["merge_percent"], NaN unless done (:154-163)  */
+  uint8_t *action_mask;     /* [E][N][5] info["action_mask"]  (abstract.py:474-481)        */
+  double *trace;            /* [3][MM_T_COUNT][E*N] per-sub-step trace (tests only) or NULL */
+} MMStepOut;
+
+/* planes of the optional per-sub-step trace (NaN where a sub-step did not run) */
+enum {
+  MM_T_X = 0, MM_T_Y, MM_T_HEADING, MM_T_SPEED,
+  MM_T_ACT_STEER, MM_T_ACT_ACC,   /* self.action after clip_actions            */
+  MM_T_SAFE_STEER, MM_T_SAFE_ACC, /* safe_action actually integrated            */
+  MM_T_LANE, MM_T_TARGET_LANE, MM_T_CRASHED, MM_T_FLAGS,
+  MM_T_QP_ROWS,                   /* 0 = shield did not run, else 3 | 4         */
+  MM_T_QP_A,                      /* G[0][0] = g_e.vx * dt                      */
+  MM_T_QP_H0, MM_T_QP_H1, MM_T_QP_H2, MM_T_QP_H3, /* h vector (H3 NaN if 3 rows) */
+  MM_T_QP_D,                      /* u_bar[0] returned by the QP                */
+  MM_T_COUNT
+};
+
+typedef struct MMHandle_ *MMHandle;
+typedef void *MMStream; /* hipStream_t for libmm_hip, ignored by the oracle */
+
+/* error codes (mirrors the exceptions of SURVEY 8b "errors") */
+#define MM_OK 0
+#define MM_ERR_INVALID_ARG (-1)   /* ValueError: unknown safety / env type, bad sizes      */
+#define MM_ERR_NOT_READY (-2)     /* NotImplementedError: road / vehicles not initialised  */
+#define MM_ERR_DEVICE (-3)        /* HIP runtime failure (message in mm_last_error)        */
+#define MM_ERR_QP_BOUNDS (-4)     /* ValueError of CBFType.check_bounds (cbf.py:87-96)     */
+
+int32_t mm_abi_version(void);
+
+/* Byte layout of the caller-owned state buffer for E envs x N agents. */
+int32_t mm_state_layout(int32_t E, int32_t N, MMStateLayout *out);
+
+/*
+ * Construction = gym.make(id) + the env.config[...] writes of run_mappo.py:143-171.
+ * `state` (DEV, layout above, >= total_bytes, 256-B aligned) is borrowed until mm_destroy.
+ * `first_env` is the global index of local env 0 (multi-GPU sharding: RNG streams are keyed on
+ * first_env + e, so a batch sharded over ranks draws the same episodes as one big batch).
+ */
+int32_t mm_create(const MMConfig *cfg, int32_t E, int32_t N, int32_t device, void *state,
+                  uint64_t state_bytes, int64_t first_env, MMHandle *out);
+int32_t mm_destroy(MMHandle h);
+/* env.config[...] = ... after construction (takes effect from the next call). */
+int32_t mm_set_config(MMHandle h, const MMConfig *cfg);
+
+/*
+ * reset(): AbstractEnv.reset (abstract.py:176-209) for the envs selected by env_mask (DEV
+ * uint8[E], NULL = all).  Spawns N/2 vehicles on ab0 and N - N/2 on jk0 with the counter-based
+ * device RNG (seeds DEV uint64[E] or NULL -> cfg.seed + first_env + e), then observes.
+ * obs: DEV [E][N][5F]; avail: DEV uint8 [E][N][5] (NULL ok).
+ */
+int32_t mm_reset(MMHandle h, const uint8_t *env_mask, const uint64_t *seeds, void *obs,
+                 uint8_t *avail, MMStream stream);
+
+/*
+ * Finish a reset whose kinematic state (x, y, heading, speed of every agent + KIND) the caller
+ * wrote into the state buffer (host-side numpy-compatible spawn, fixtures): derives lane,
+ * target lane, speed index / target speed exactly as Vehicle/ControlledVehicle/MDPVehicle.__init__
+ * do (kinematics.py:36-53, controller.py:35-50,277-291), clears episode counters and histories.
+ */
+int32_t mm_init_from_kinematics(MMHandle h, const uint8_t *env_mask, MMStream stream);
+
+/* observation_type.observe() (+ action mask) of the current state; no state change. */
+int32_t mm_observe(MMHandle h, void *obs, uint8_t *avail, MMStream stream);
+
+/*
+ * step(): MergeEnv.step (merge_env_v1.py:126-166).  actions: DEV int32[E][N] in 0..4.
+ * `out` is a HOST struct of DEV pointers.
+ */
+int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStream stream);
+
+/*
+ * Stand-alone batched shield QP (unit parity of cbf.py:110-161 + cvxopt.solvers.qp):
+ *   min 1/2 (d^2 + e^2 + 1e18 s^2)  s.t.  G u <= h,  u = (d, e, s),
+ * G: DEV double[n][4][3] row-major, h: DEV double[n][4], rows: DEV int32[n] (3 or 4).
+ * u_out: DEV double[n][3]; status: DEV uint8[n] (1 = optimal).
+ */
+int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec,
+                     const int32_t *rows, double *u_out, uint8_t *status, MMStream stream);
+
+/*
+ * Rollout metric accumulator (the only cross-GPU quantity): adds this step's
+ * {sum reward, crashed episodes, sum average_speed, sum traffic_speed, env-steps, sum merge %,
+ *  finished episodes} into metrics[0..6] and min-reduces min_headway into metrics[7].
+ * metrics: DEV double[8], caller-initialised (zeros, +inf).  Optional.
+ */
+int32_t mm_set_metrics_buffer(MMHandle h, double *metrics);
+
+const char *mm_last_error(MMHandle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MM_ABI_H */

@@ -1,0 +1,168 @@
+"""ctypes binding of the C ABI in include/mm_abi.h (the drop-in boundary).
+
+Pure plumbing: structures, prototypes and error mapping.  The same binding serves the HIP
+library (device pointers) and -- from tests only -- the CPU oracle (host pointers); which
+shared object is loaded is decided by the caller, never silently.
+"""
+import ctypes as C
+import os
+
+MM_ABI_VERSION = 1
+MM_MAX_AGENTS = 16
+ENV_V0, ENV_V1 = 0, 1
+SHIELD_NONE, SHIELD_HSS, SHIELD_MASS = 0, 1, 2
+
+# plane indices (keep in sync with include/mm_abi.h; checked by tests/test_abi.py)
+F_PLANES = ["X", "Y", "HEADING", "SPEED", "TARGET_SPEED", "SAFE_STEER", "SAFE_ACC", "G_VX",
+            "H1_X", "H1_HEADING", "H1_VX", "H1_SPEED", "H2_X", "H2_HEADING", "H2_VX", "H2_SPEED"]
+B_PLANES = ["LANE", "TARGET_LANE", "SPEED_INDEX", "CRASHED", "HL_ACTION", "FLAGS", "HIST_LEN", "KIND"]
+E_PLANES = ["STEPS", "TIME", "N_MERGE", "EPISODE"]
+T_PLANES = ["X", "Y", "HEADING", "SPEED", "ACT_STEER", "ACT_ACC", "SAFE_STEER", "SAFE_ACC", "LANE",
+            "TARGET_LANE", "CRASHED", "FLAGS", "QP_ROWS", "QP_A", "QP_H0", "QP_H1", "QP_H2", "QP_H3",
+            "QP_D"]
+F = {n: i for i, n in enumerate(F_PLANES)}
+B = {n: i for i, n in enumerate(B_PLANES)}
+EP = {n: i for i, n in enumerate(E_PLANES)}
+T = {n: i for i, n in enumerate(T_PLANES)}
+
+FLAG_COLLABORATE_ADJ, FLAG_IS_LC_SAFE, FLAG_IS_COLLABORATING = 1, 2, 4
+HL_NONE = 255
+
+MM_OK, MM_ERR_INVALID_ARG, MM_ERR_NOT_READY, MM_ERR_DEVICE, MM_ERR_QP_BOUNDS = 0, -1, -2, -3, -4
+
+# (from, to, id) lane tuples of the reference <-> lane ids (merge_env_v1.py:231-245)
+LANE_INDEX = [("a", "b", 0), ("b", "c", 0), ("b", "c", 1), ("c", "d", 0), ("j", "k", 0), ("k", "b", 0)]
+LANE_ID = {l: i for i, l in enumerate(LANE_INDEX)}
+
+
+class MMStateLayout(C.Structure):
+    _fields_ = [("f64_offset", C.c_uint64), ("u8_offset", C.c_uint64), ("env_offset", C.c_uint64),
+                ("seed_offset", C.c_uint64), ("total_bytes", C.c_uint64)]
+
+
+class MMConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("env_kind", C.c_int32), ("shield", C.c_int32),
+                ("simulation_frequency", C.c_int32), ("policy_frequency", C.c_int32),
+                ("duration", C.c_int32), ("action_masking", C.c_int32), ("auto_reset", C.c_int32),
+                ("obs_f64", C.c_int32), ("reserved0", C.c_int32),
+                ("collision_reward", C.c_double), ("high_speed_reward", C.c_double),
+                ("headway_cost", C.c_double), ("headway_time", C.c_double),
+                ("merging_lane_cost", C.c_double), ("reward_speed_lo", C.c_double),
+                ("reward_speed_hi", C.c_double), ("cbf_eta", C.c_double), ("cbf_tau", C.c_double),
+                ("seed", C.c_uint64)]
+
+
+class MMStepOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "obs", "reward", "done", "agents_rewards", "regional_rewards", "agents_dones", "agents_info",
+        "crashed", "average_speed", "traffic_speed", "min_headway", "merge_percent", "action_mask",
+        "trace")]
+
+
+def shield_from_safety_guarantee(value):
+    """config["safety_guarantee"] -> shield id, as safe_controller.py:229-241 + decentral_layer.py:767-817
+    dispatch it.  Unknown "cbf-*" types raise ValueError like safety_layer does."""
+    if value in (None, "none", "priority", "dmc") or "cbf-" not in value:
+        # 'priority' / 'dmc' are the competing baselines (out of scope): the
+        # vehicle-level shield is off for them exactly as in get_safe_action.
+        return SHIELD_NONE
+    kind = value.split("-")[1]
+    if kind in ("hss", "av", "avs", "avs_cint"):
+        return SHIELD_HSS
+    if kind in ("mass", "cav"):
+        return SHIELD_MASS
+    raise ValueError("Undefined safety_type:{0}".format(kind))
+
+
+def default_env_config(env_id):
+    """Default config of the registered envs (merge_env_v1.py:33-57, :389-437, abstract.py:106-133)."""
+    cfg = {
+        "simulation_frequency": 15, "policy_frequency": 5, "duration": 20,
+        "reward_speed_range": [10, 30], "COLLISION_REWARD": 200, "HIGH_SPEED_REWARD": 1,
+        "HEADWAY_COST": 4, "HEADWAY_TIME": 1.2, "MERGING_LANE_COST": 4, "traffic_density": 1,
+        "safety_guarantee": "priority", "seed": 0, "action_masking": True, "mixed_traffic": True,
+        "controlled_vehicles": 4,
+    }
+    if env_id == "merge-multi-agent-v1":
+        cfg.update({"action_masking": False, "lateral_control": "steer", "traffic_type": "cav",
+                    "agent_reward": "default"})
+    elif env_id != "merge-multi-agent-v0":
+        raise ValueError("unsupported env id %r (hot path covers merge-multi-agent-v0 / -v1)" % env_id)
+    return cfg
+
+
+def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0):
+    """env.config dict (+ CBFType.GAMMA_B / CBFType.TAU, run_mappo.py:138-139) -> MMConfig."""
+    c = MMConfig()
+    c.abi_version = MM_ABI_VERSION
+    c.env_kind = ENV_V1 if env_id == "merge-multi-agent-v1" else ENV_V0
+    c.shield = shield_from_safety_guarantee(config.get("safety_guarantee")) if c.env_kind == ENV_V1 else SHIELD_NONE
+    if c.env_kind == ENV_V1 and config.get("lateral_control", "steer") != "steer":
+        raise AttributeError("Lateral control: {0} is not supported".format(config.get("lateral_control")))
+    c.simulation_frequency = int(config["simulation_frequency"])
+    c.policy_frequency = int(config["policy_frequency"])
+    c.duration = int(config["duration"])
+    c.action_masking = int(bool(config.get("action_masking", False)))
+    c.auto_reset = int(bool(auto_reset))
+    c.obs_f64 = int(bool(obs_f64))
+    c.collision_reward = float(config["COLLISION_REWARD"])
+    c.high_speed_reward = float(config["HIGH_SPEED_REWARD"])
+    c.headway_cost = float(config["HEADWAY_COST"])
+    c.headway_time = float(config["HEADWAY_TIME"])
+    c.merging_lane_cost = float(config["MERGING_LANE_COST"])
+    c.reward_speed_lo = float(config["reward_speed_range"][0])
+    c.reward_speed_hi = float(config["reward_speed_range"][1])
+    c.cbf_eta = float(cbf_eta)
+    c.cbf_tau = float(config["HEADWAY_TIME"] if cbf_tau is None else cbf_tau)
+    c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    return c
+
+
+class CLib(object):
+    """One loaded implementation of include/mm_abi.h."""
+
+    SYMBOLS = ["mm_abi_version", "mm_state_layout", "mm_create", "mm_destroy", "mm_set_config",
+               "mm_reset", "mm_init_from_kinematics", "mm_observe", "mm_step", "mm_shield_qp",
+               "mm_set_metrics_buffer", "mm_last_error"]
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise FileNotFoundError(
+                "%s is missing: build it first (python -c 'import __graft_entry__ as g; g.build()')" % path)
+        self.path = path
+        self.lib = lib = C.CDLL(path)
+        vp, i32, u64, i64 = C.c_void_p, C.c_int32, C.c_uint64, C.c_int64
+        lib.mm_abi_version.restype = i32
+        lib.mm_state_layout.argtypes = [i32, i32, C.POINTER(MMStateLayout)]
+        lib.mm_create.argtypes = [C.POINTER(MMConfig), i32, i32, i32, vp, u64, i64, C.POINTER(vp)]
+        lib.mm_destroy.argtypes = [vp]
+        lib.mm_set_config.argtypes = [vp, C.POINTER(MMConfig)]
+        lib.mm_reset.argtypes = [vp, vp, vp, vp, vp, vp]
+        lib.mm_init_from_kinematics.argtypes = [vp, vp, vp]
+        lib.mm_observe.argtypes = [vp, vp, vp, vp]
+        lib.mm_step.argtypes = [vp, vp, C.POINTER(MMStepOut), vp]
+        lib.mm_shield_qp.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+        lib.mm_set_metrics_buffer.argtypes = [vp, vp]
+        lib.mm_last_error.argtypes = [vp]
+        lib.mm_last_error.restype = C.c_char_p
+        for s in self.SYMBOLS:
+            if s not in ("mm_abi_version", "mm_last_error"):
+                getattr(lib, s).restype = i32
+        if lib.mm_abi_version() != MM_ABI_VERSION:
+            raise RuntimeError("ABI version mismatch in %s" % path)
+
+    def check(self, rc, handle=None):
+        """Map C status codes to the exception types the reference raises (SURVEY 8b 'errors')."""
+        if rc == MM_OK:
+            return
+        msg = self.lib.mm_last_error(handle).decode() if handle else ""
+        if rc in (MM_ERR_INVALID_ARG, MM_ERR_QP_BOUNDS):
+            raise ValueError(msg or "invalid argument")
+        if rc == MM_ERR_NOT_READY:
+            raise NotImplementedError(msg or "The road and vehicle must be initialized in the environment implementation")
+        raise RuntimeError("mm error %d: %s" % (rc, msg))
+
+    def state_layout(self, E, N):
+        lay = MMStateLayout()
+        self.check(self.lib.mm_state_layout(E, N, C.byref(lay)))
+        return lay

@@ -1,0 +1,336 @@
+"""Drop-in adapter with the reference's gym-0.14 style Env surface.
+
+`MergeEnvCompat` is a batch-of-1 view of the batched engine exposing exactly what
+marl/mappo.py and run_mappo.py touch: `reset`, `step`, `config[...]`, `seed`, `n_s`, `n_a`, `T`,
+`controlled_vehicles`, `road.vehicles`, `is_crashed()`, `close()`, `ACTIONS_ALL`, `unwrapped`.
+The episode spawn replays the reference's *global* numpy RNG call sequence (abstract.py:182-187,
+merge_env_v1.py:180-211,265-364) so that a MAPPO loop seeded the same way sees the same episodes
+and the same downstream `np.random` stream.
+
+`CBFType`, `cbf_factory`, `safety_layer` are the same-named shims of the shield interface
+(cbf.py:433-440, decentral_layer.py:767-817): they pack the QP and call the batched C entry.
+"""
+import random
+
+import numpy as np
+import torch
+
+from . import _cabi as abi
+from .vec_env import VecMergeEnv
+
+MAX_VEHICLES = 12  # 6 + 6 spawn slots (merge_env_v1.py:284-285)
+
+
+class CBFType(object):
+    """Class-level knobs the reference sets from the .ini (cbf.py:18,24; run_mappo.py:138-139)."""
+    GAMMA_B = 0
+    TAU = 0.5
+    ADJ_BUFFER = 2.0134
+    ACCELERATION_RANGE = (-12.5, 6)
+
+
+class _VehicleView(object):
+    """Read-only window on one agent of the device state (what callers read off a vehicle)."""
+    LENGTH, WIDTH = 5.0, 2.0
+
+    def __init__(self, env, index):
+        self._env, self.id = env, index
+
+    def _f(self, name):
+        return float(self._env._b.f64[abi.F[name], 0, self.id])
+
+    def _b(self, name):
+        return int(self._env._b.u8[abi.B[name], 0, self.id])
+
+    @property
+    def position(self):
+        return np.array([self._f("X"), self._f("Y")])
+
+    heading = property(lambda s: s._f("HEADING"))
+    speed = property(lambda s: s._f("SPEED"))
+    target_speed = property(lambda s: s._f("TARGET_SPEED"))
+    crashed = property(lambda s: bool(s._b("CRASHED")))
+    speed_index = property(lambda s: s._b("SPEED_INDEX"))
+    lane_index = property(lambda s: abi.LANE_INDEX[s._b("LANE")])
+    target_lane_index = property(lambda s: abi.LANE_INDEX[s._b("TARGET_LANE")])
+    collaborate_adj = property(lambda s: bool(s._b("FLAGS") & abi.FLAG_COLLABORATE_ADJ))
+    is_lc_safe = property(lambda s: bool(s._b("FLAGS") & abi.FLAG_IS_LC_SAFE))
+    is_collaborating = property(lambda s: bool(s._b("FLAGS") & abi.FLAG_IS_COLLABORATING))
+
+    @property
+    def velocity(self):
+        return self.speed * np.array([np.cos(self.heading), np.sin(self.heading)])
+
+    @property
+    def safe_action(self):
+        return {"steering": self._f("SAFE_STEER"), "acceleration": self._f("SAFE_ACC")}
+
+
+class _Obstacle(object):
+    LENGTH = WIDTH = 2.0
+    position = np.array([420.0, 4.0])
+    heading = 0.0
+    speed = 0.0
+
+
+class _Road(object):
+    def __init__(self):
+        self.vehicles = []
+        self.objects = [_Obstacle()]
+
+
+class MergeEnvCompat(object):
+    """gym.make("merge-multi-agent-v0" | "-v1") replacement; see module docstring."""
+
+    n_a = 5
+    metadata = {"render.modes": []}
+
+    def __init__(self, env_id="merge-multi-agent-v0", config=None, backend_factory=None, device="cuda:0"):
+        self.env_id = env_id
+        self.config = abi.default_env_config(env_id)
+        if config:
+            self.config.update(config)
+        self.n_s = 30 if env_id == "merge-multi-agent-v1" else 25
+        self.seed = self.config["seed"]
+        self.ACTIONS_ALL = {"LANE_LEFT": 0, "IDLE": 1, "LANE_RIGHT": 2, "FASTER": 3, "SLOWER": 4}
+        self.ends = [220, 100, 100, 1000]
+        self._factory = backend_factory or (lambda **kw: VecMergeEnv(device=device, **kw))
+        self._b = None
+        self.road = None
+        self.controlled_vehicles = []
+        self.time = self.steps = 0
+        self.done = False
+        self.n_merge = 0
+        self.T = int(self.config["duration"] * self.config["policy_frequency"])
+        self.reset()  # abstract.py:86
+
+    unwrapped = property(lambda self: self)
+
+    # -- spawn: merge_env_v1.py:180-211 (+ :476-495 for v1) -------------------------------
+    def _num_vehicles(self, num_CAV=0):
+        cfg = self.config
+        if self.env_id == "merge-multi-agent-v1":
+            tt = cfg.get("traffic_type", "cav")
+            if tt == "mixed":
+                cfg["mixed_traffic"] = True
+            elif tt == "cav":
+                cfg["mixed_traffic"] = False
+            elif tt in ("av", "hdv"):
+                raise NotImplementedError("traffic_type=%r needs HDVs (IDM/MOBIL), not on the hot path yet" % tt)
+        num_HDV = 0
+        lo_hi = {1: ((1, 4), (1, 4)), 2: ((2, 5), (2, 5)), 3: ((4, 7), (3, 6))}.get(cfg["traffic_density"])
+        if lo_hi:
+            if num_CAV == 0:
+                num_CAV = np.random.choice(np.arange(*lo_hi[0]), 1)[0]
+            num_HDV = np.random.choice(np.arange(*lo_hi[1]), 1)[0]
+        if cfg.get("mixed_traffic") is not None and not cfg["mixed_traffic"]:
+            num_CAV, num_HDV = num_CAV + num_HDV, 0
+        return int(num_CAV), int(num_HDV)
+
+    def _make_vehicles(self, num_CAV, num_HDV):
+        """merge_env_v1.py:265-364, CAV part; same global-RNG draws in the same order."""
+        if num_HDV:
+            raise NotImplementedError("mixed traffic (HDVs) is not on the hot path yet (SURVEY 8f-2)")
+        if num_CAV > MAX_VEHICLES:
+            raise ValueError("at most %d vehicles (6 + 6 spawn slots)" % MAX_VEHICLES)
+        spawn_points_s = [10, 60, 110, 160, 210, 260]
+        spawn_points_m = [5, 55, 105, 155, 205, 255]
+        num_s_c = num_CAV // 2 if num_CAV != 1 else np.random.choice(2)
+        num_m_c = num_CAV - num_s_c
+        spawn_point_s_c = list(np.random.choice(spawn_points_s, num_s_c, replace=False))
+        spawn_point_m_c = list(np.random.choice(spawn_points_m, num_m_c, replace=False))
+        for a in spawn_point_s_c:
+            spawn_points_s.remove(a)
+        for b in spawn_point_m_c:
+            spawn_points_m.remove(b)
+        # the HDV draws still happen in the reference with sizes 0 (num_HDV // 2 == 0)
+        np.random.choice(spawn_points_s, 0, replace=False)
+        np.random.choice(spawn_points_m, 0, replace=False)
+        initial_speed = list(np.random.rand(num_CAV + num_HDV) * 2 + 25)
+        loc_noise = list(np.random.rand(num_CAV + num_HDV) * 8 - 4)
+        x, y, v = [], [], []
+        for _ in range(num_s_c):
+            x.append(spawn_point_s_c.pop(0) + loc_noise.pop(0)); y.append(0.0); v.append(initial_speed.pop(0))
+        for _ in range(num_m_c):
+            x.append(spawn_point_m_c.pop(0) + loc_noise.pop(0)); y.append(6.5 + 4); v.append(initial_speed.pop(0))
+        return np.array(x, dtype=np.float64), np.array(y), np.array(v, dtype=np.float64), int(num_m_c)
+
+    def _backend(self):
+        if self._b is None:
+            self._b = self._factory(E=1, N=MAX_VEHICLES, env_id=self.env_id, config=self.config,
+                                    cbf_eta=CBFType.GAMMA_B, cbf_tau=CBFType.TAU, obs_f64=True)
+        return self._b
+
+    # -- Env API ------------------------------------------------------------------------------
+    def reset(self, is_training=True, testing_seeds=0, num_CAV=0):
+        """abstract.py:176-209 -> (obs[n_agents, n_s] float64, available_actions[n_agents, 5])."""
+        if is_training:
+            np.random.seed(self.seed)
+            random.seed(self.seed)
+        else:
+            np.random.seed(testing_seeds)
+            random.seed(testing_seeds)
+        self.time = self.steps = 0
+        self.seed += 1
+        self.done = False
+        self.vehicle_speed, self.vehicle_pos = [], []
+        n_cav, n_hdv = self._num_vehicles(num_CAV=num_CAV)
+        x, y, v, n_merge = self._make_vehicles(n_cav, n_hdv)
+        self.n_merge = n_merge
+        self.T = int(self.config["duration"] * self.config["policy_frequency"])
+        b = self._backend()
+        b.configure(self.config, cbf_eta=CBFType.GAMMA_B, cbf_tau=CBFType.TAU)
+        self._n = n = len(x)
+        pad = lambda a, fill: np.concatenate([a, np.full(MAX_VEHICLES - n, fill)])  # noqa: E731
+        obs, avail = b.set_kinematics(pad(x, np.nan)[None], pad(y, 0.0)[None], np.zeros((1, MAX_VEHICLES)),
+                                      pad(v, 0.0)[None], n_merge=np.array([n_merge]))
+        self.road = _Road()
+        self.controlled_vehicles = [_VehicleView(self, i) for i in range(n)]
+        self.road.vehicles = list(self.controlled_vehicles)
+        return (obs[0, :n].cpu().numpy().astype(np.float64).reshape(n, -1),
+                avail[0, :n].cpu().numpy().astype(np.int64))
+
+    @property
+    def vehicle(self):
+        return self.controlled_vehicles[0] if self.controlled_vehicles else None
+
+    def step(self, action):
+        """merge_env_v1.py:126-166 / abstract.py:443-510 -> (obs, reward, done, info)."""
+        if self.road is None or self.vehicle is None:
+            raise NotImplementedError("The road and vehicle must be initialized in the environment implementation")
+        n = self._n
+        action = tuple(int(a) for a in action)
+        assert len(action) == n
+        b = self._b
+        act = torch.ones(1, MAX_VEHICLES, dtype=torch.int32)
+        act[0, :n] = torch.tensor(action, dtype=torch.int32)
+        obs, reward, done, out = b.step(act.to(b.device))
+        self.steps += 1
+        self.time = int(b.env_i32[abi.EP["TIME"], 0])
+        o = {k: v[0].cpu().numpy() for k, v in out.items()}
+        terminal = bool(o["done"])
+        speeds = o["agents_info"][:n, 2]
+        self.vehicle_speed.append([float(s) for s in speeds])
+        self.vehicle_pos.append([float(p) for p in o["agents_info"][:n, 0]])
+        info = {
+            "speed": float(speeds[0]), "crashed": bool(o["crashed"][0]), "action": action,
+            "new_action": action, "action_mask": o["action_mask"][:n].astype(np.int64),
+            "average_speed": float(o["average_speed"]),
+            "vehicle_speed": np.array(self.vehicle_speed), "vehicle_position": np.array(self.vehicle_pos),
+            "agents_dones": tuple(bool(d) for d in o["agents_dones"][:n]),
+            "agents_info": [[float(a) for a in row] for row in o["agents_info"][:n]],
+            "agents_rewards": tuple(float(r) for r in o["agents_rewards"][:n]),
+            "regional_rewards": tuple(float(r) for r in o["regional_rewards"][:n]),
+            "traffic_speed": float(o["traffic_speed"]), "min_headway": float(o["min_headway"]),
+        }
+        if terminal:
+            info["merge_percent"] = float(o["merge_percent"])
+        return (obs[0, :n].cpu().numpy().astype(np.float64).reshape(n, -1), float(o["reward"]), terminal, info)
+
+    def is_crashed(self):
+        return any(v.crashed for v in self.controlled_vehicles)
+
+    def render(self, mode="human"):
+        raise NotImplementedError("pygame rendering is outside the hot path (SURVEY 2 row 11)")
+
+    def close(self):
+        self.done = True
+
+
+def make(env_id, **kw):
+    """gym.make counterpart for the two env ids on the hot path (merge_env_v1.py:681-689)."""
+    return MergeEnvCompat(env_id, **kw)
+
+
+# ---------------------------------------------------------------------------------------------
+# shield interface shims (cbf.py / decentral_layer.py)
+# ---------------------------------------------------------------------------------------------
+class _CBF(object):
+    """CBF_AV / CBF_CAV counterpart (cbf.py:196-430): row assembly on the host, solve on the device."""
+    STATE_SPACE = ["x", "heading"]
+    ACCELERATION_RANGE = (-12.5, 6)
+
+    def __init__(self, action_size, action_bound, vehicle_size, vehicle_lane=0, is_ma=False, solver=None):
+        self.action_size, self.action_bound, self.vehicle_size = action_size, action_bound, vehicle_size
+        self.is_ma_dynamics, self.constrain_adj = is_ma, False
+        self.safe_dists = [0, 0, 0]
+        self.is_optimal = self.is_safe = self.is_invariant = None
+        self.p_lon = np.array([-1, 0, 1, 0, 0, 0, 0, 0.0])
+        self.p_lona = np.array([-1, 0, 0, 0, 1, 0, 0, 0.0])
+        self.p_lonr = np.array([1, 0, 0, 0, 0, 0, -1, 0.0])
+        self._solver = solver
+
+    def define_pq(self, x=None):
+        self.q_lon = -self.vehicle_size[0] - self.safe_dists[0]
+        self.q_lona = -self.vehicle_size[0] - self.safe_dists[1]
+        self.q_lonr = -self.vehicle_size[0] - self.safe_dists[2]
+        if self.is_ma_dynamics and self.constrain_adj:
+            self.q_lona = -self.vehicle_size[0] - self.safe_dists[1] - CBFType.ADJ_BUFFER
+
+    def get_G(self, g):
+        G = np.array([np.append(-np.dot(self.p_lon, g[:, :2]), -1.0), [1, 0, 0], [-1, 0, 0]], dtype=float)
+        if self.is_ma_dynamics and self.constrain_adj:
+            G = np.vstack([G, np.append(-np.dot(self.p_lona, g[:, :2]), -1.0)])
+        return G
+
+    def _row(self, p, q, f, g, x, u, eta):
+        return np.dot(p, f) + (eta - 1) * np.dot(p, x) + eta * q + np.dot(p, np.squeeze(np.dot(g, u)))
+
+    def get_h(self, f, g, x, u_ll, eta=None):
+        eta = CBFType.GAMMA_B if eta is None else eta
+        h = [self._row(self.p_lon, self.q_lon, f, g, x, u_ll, eta),
+             self.action_bound[0][1] - u_ll[0], -self.action_bound[0][0] + u_ll[0]]
+        if self.is_ma_dynamics and self.constrain_adj:
+            h.append(self._row(self.p_lona, self.q_lona, f, g, x, u_ll, eta))
+        return np.array(h, dtype=float)
+
+    def control_barrier(self, u_ll, f, g, x, dt=0):
+        """cbf.py:110-161: returns u_safe[2]; the QP runs in the batched device solver."""
+        u_ll = np.squeeze(np.asarray(u_ll, dtype=float))
+        self.define_pq(x)
+        G, h = self.get_G(g), self.get_h(f, g, x, u_ll)
+        Gp, hp = np.zeros((1, 4, 3)), np.zeros((1, 4))
+        Gp[0, :G.shape[0]], hp[0, :h.shape[0]] = G, h
+        solver = self._solver or _default_solver()
+        u_bar, status = solver.shield_qp(Gp, hp, np.array([G.shape[0]], dtype=np.int32))
+        u_bar = u_bar[0].cpu().numpy()
+        u_safe = u_ll[:2] + u_bar[:2]
+        if u_safe[0] - 0.001 > self.action_bound[0][1] or u_safe[0] + 0.001 < self.action_bound[0][0]:
+            raise ValueError("Error in QP. Invalid accceleration: {0}".format(u_safe[0]))
+        self.is_optimal = bool(status[0])
+        return np.array(u_safe)
+
+    def get_status(self):
+        return {"is_optimal": float(bool(self.is_optimal))}
+
+
+_SOLVER = None
+
+
+def _default_solver():
+    global _SOLVER
+    if _SOLVER is None:
+        _SOLVER = VecMergeEnv(E=1, N=2)
+    return _SOLVER
+
+
+def cbf_factory(cbf_type, solver=None, **kwargs):
+    """cbf.py:433-440."""
+    if cbf_type in ("hss", "av", "avs", "avs_cint"):
+        return _CBF(is_ma=False, solver=solver, **kwargs)
+    elif cbf_type in ("mass", "cav"):
+        return _CBF(is_ma=True, solver=solver, **kwargs)
+    raise ValueError("Undefined cbf_type:{0}".format(cbf_type))
+
+
+def safety_layer(safety_type, action, vehicle, dt, safe_dist="theadway", **kwargs):
+    """decentral_layer.py:767-817 signature.  In this engine the shield runs fused inside `step`
+    (per sub-step, front-to-back); a per-vehicle stand-alone evaluation on device state is exposed
+    through the trace of a step (MMStepOut.trace), not through Python objects."""
+    if safety_type not in ("hss", "av", "avs", "avs_cint", "mass", "cav"):
+        raise ValueError("Undefined safety_type:{0}".format(safety_type))
+    if safe_dist != "theadway":
+        raise ValueError("safe_dist type {} not supported".format(safe_dist))
+    raise NotImplementedError(
+        "stand-alone safety_layer() on Python vehicle objects: use MergeEnvCompat.step (fused shield) "
+        "or cbf_factory(...).control_barrier for a single QP")

@@ -1,0 +1,202 @@
+"""Batched merge environment on PyTorch tensors over the C ABI (host side of the hot path).
+
+`VecMergeEnv` is the product class: E independent episodes x N CAVs live as a struct of arrays in
+HBM and every reset/step is ONE call into libmm_hip.so (hand-written HIP, gfx950).  It refuses
+to run without that library and a GPU -- there is no CPU fallback.
+
+`BatchedMergeEnv` is the device-agnostic plumbing (state views, output buffers, ctypes calls); the
+tests also drive it with the CPU oracle library on host tensors to check parity.
+
+Mirrors the reference's Env API batched over E: reset -> (obs[E,N,n_s], avail[E,N,5]),
+step(actions[E,N]) -> (obs, reward[E], done[E], info{...tensors...}).
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import _cabi as abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(_HERE, "csrc", "libmm_hip.so")
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedMergeEnv(object):
+    n_a = 5  # merge_env_v1.py:27
+
+    def __init__(self, clib, E, N, env_id="merge-multi-agent-v1", config=None, device="cpu",
+                 cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0, first_env=0,
+                 trace=False):
+        self.clib, self.E, self.N = clib, int(E), int(N)
+        self.env_id = env_id
+        self.device = torch.device(device)
+        self.config = abi.default_env_config(env_id)
+        if config:
+            self.config.update(config)
+        self.cbf_eta, self.cbf_tau = cbf_eta, cbf_tau
+        self.auto_reset, self.obs_f64, self.seed = auto_reset, obs_f64, seed
+        self.n_f = 6 if env_id == "merge-multi-agent-v1" else 5
+        self.n_s = 5 * self.n_f  # merge_env_v1.py:28 / :413
+        self._cfg = self._make_cfg()
+        self.T = int(self.config["duration"] * self.config["policy_frequency"])
+        lay = self.layout = clib.state_layout(self.E, self.N)
+        A = self.E * self.N
+        dev = self.device
+        raw = self._raw_state = torch.zeros(lay.total_bytes + 256, dtype=torch.uint8, device=dev)
+        skew = (-raw.data_ptr()) % 256  # hipMalloc is 256-B aligned already; host tensors are not
+        self.state = raw[skew: skew + lay.total_bytes]
+        assert self.state.data_ptr() % 256 == 0
+        self.f64 = self.state[lay.f64_offset: lay.f64_offset + 8 * A * len(abi.F_PLANES)].view(
+            torch.float64).view(len(abi.F_PLANES), self.E, self.N)
+        self.u8 = self.state[lay.u8_offset: lay.u8_offset + A * len(abi.B_PLANES)].view(
+            len(abi.B_PLANES), self.E, self.N)
+        self.env_i32 = self.state[lay.env_offset: lay.env_offset + 4 * self.E * len(abi.E_PLANES)].view(
+            torch.int32).view(len(abi.E_PLANES), self.E)
+        self.seeds = self.state[lay.seed_offset: lay.seed_offset + 8 * self.E].view(torch.int64)
+        odt = torch.float64 if obs_f64 else torch.float32
+        z = lambda *s, dtype=torch.float64: torch.zeros(*s, dtype=dtype, device=dev)  # noqa: E731
+        self.obs = z(self.E, self.N, self.n_s, dtype=odt)
+        self.avail = z(self.E, self.N, 5, dtype=torch.uint8)
+        self.out = {
+            "reward": z(self.E), "done": z(self.E, dtype=torch.uint8),
+            "agents_rewards": z(self.E, self.N), "regional_rewards": z(self.E, self.N),
+            "agents_dones": z(self.E, self.N, dtype=torch.uint8), "agents_info": z(self.E, self.N, 3),
+            "crashed": z(self.E, self.N, dtype=torch.uint8), "average_speed": z(self.E),
+            "traffic_speed": z(self.E), "min_headway": z(self.E), "merge_percent": z(self.E),
+            "action_mask": z(self.E, self.N, 5, dtype=torch.uint8),
+        }
+        self.trace = z(3, len(abi.T_PLANES), self.E, self.N) if trace else None
+        self.metrics = None
+        self._step_out = abi.MMStepOut()
+        self._step_out.obs = self.obs.data_ptr()
+        for k, t in self.out.items():
+            setattr(self._step_out, k, t.data_ptr())
+        self._step_out.trace = self.trace.data_ptr() if trace else None
+        self._h = C.c_void_p()
+        index = self.device.index if self.device.type == "cuda" else 0
+        clib.check(clib.lib.mm_create(C.byref(self._cfg), self.E, self.N, index or 0,
+                                      _ptr(self.state), lay.total_bytes, int(first_env),
+                                      C.byref(self._h)))
+
+    # -- configuration ------------------------------------------------------------------
+    def _make_cfg(self):
+        return abi.make_config(self.env_id, self.config, cbf_eta=self.cbf_eta, cbf_tau=self.cbf_tau,
+                               auto_reset=self.auto_reset, obs_f64=self.obs_f64, seed=self.seed)
+
+    def configure(self, config=None, **kw):
+        """env.config[k] = v after construction (run_mappo.py:145-171); CBFType globals via kw."""
+        if config:
+            self.config.update(config)
+        for k in ("cbf_eta", "cbf_tau", "auto_reset", "seed"):
+            if k in kw:
+                setattr(self, k, kw[k])
+        self._cfg = self._make_cfg()
+        self.T = int(self.config["duration"] * self.config["policy_frequency"])
+        self.clib.check(self.clib.lib.mm_set_config(self._h, C.byref(self._cfg)), self._h)
+
+    def _stream(self):
+        if self.device.type == "cuda":
+            return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return None
+
+    # -- Env API --------------------------------------------------------------------------
+    def reset(self, env_mask=None, seeds=None):
+        """AbstractEnv.reset (abstract.py:176-209) with the device RNG, for all / masked envs."""
+        if env_mask is not None:
+            env_mask = env_mask.to(self.device, torch.uint8).contiguous()
+        if seeds is not None:
+            seeds = seeds.to(self.device, torch.int64).contiguous()
+        self.clib.check(self.clib.lib.mm_reset(self._h, _ptr(env_mask), _ptr(seeds), _ptr(self.obs),
+                                               _ptr(self.avail), self._stream()), self._h)
+        return self.obs, self.avail
+
+    def set_kinematics(self, x, y, heading, speed, n_merge=None, env_mask=None):
+        """Host-provided spawn (numpy-compatible reset, fixtures): [E,N] tensors; NaN x = absent."""
+        dev = self.device
+        x = torch.as_tensor(x, dtype=torch.float64, device=dev).view(self.E, self.N)
+        present = ~torch.isnan(x)
+        sel = slice(None) if env_mask is None else env_mask.to(dev).bool()
+        put = lambda plane, v: plane.__setitem__(sel, v[sel])  # noqa: E731
+        put(self.f64[abi.F["X"]], torch.nan_to_num(x))
+        put(self.f64[abi.F["Y"]], torch.as_tensor(y, dtype=torch.float64, device=dev).view(self.E, self.N))
+        put(self.f64[abi.F["HEADING"]], torch.as_tensor(heading, dtype=torch.float64, device=dev).view(self.E, self.N))
+        put(self.f64[abi.F["SPEED"]], torch.as_tensor(speed, dtype=torch.float64, device=dev).view(self.E, self.N))
+        put(self.u8[abi.B["KIND"]], present.to(torch.uint8))
+        m = None if env_mask is None else env_mask.to(dev, torch.uint8).contiguous()
+        self.clib.check(self.clib.lib.mm_init_from_kinematics(self._h, _ptr(m), self._stream()), self._h)
+        if n_merge is not None:
+            put(self.env_i32[abi.EP["N_MERGE"]], torch.as_tensor(n_merge, dtype=torch.int32, device=dev).view(self.E))
+        return self.observe()
+
+    def observe(self):
+        self.clib.check(self.clib.lib.mm_observe(self._h, _ptr(self.obs), _ptr(self.avail),
+                                                 self._stream()), self._h)
+        return self.obs, self.avail
+
+    def step(self, actions):
+        """MergeEnv.step (merge_env_v1.py:126-166) for every env; actions int32 [E, N] in 0..4."""
+        if actions.dtype != torch.int32 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(self.device, torch.int32).contiguous()
+        assert actions.numel() == self.E * self.N
+        self.clib.check(self.clib.lib.mm_step(self._h, _ptr(actions), C.byref(self._step_out),
+                                              self._stream()), self._h)
+        return self.obs, self.out["reward"], self.out["done"], self.out
+
+    def enable_metrics(self):
+        """Device-side rollout metric accumulator: 7 sums + 1 min."""
+        self.metrics = torch.zeros(8, dtype=torch.float64, device=self.device)
+        self.metrics[7] = float("inf")
+        self.clib.check(self.clib.lib.mm_set_metrics_buffer(self._h, _ptr(self.metrics)), self._h)
+        return self.metrics
+
+    def shield_qp(self, G, h, rows):
+        """Batched stand-alone shield QP (cbf.py:110-161): G [n,4,3], h [n,4], rows [n] -> u [n,3], status."""
+        dev = self.device
+        G = torch.as_tensor(G, dtype=torch.float64, device=dev).contiguous()
+        h = torch.as_tensor(h, dtype=torch.float64, device=dev).contiguous()
+        rows = torch.as_tensor(rows, dtype=torch.int32, device=dev).contiguous()
+        n = rows.numel()
+        u = torch.zeros(n, 3, dtype=torch.float64, device=dev)
+        st = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.clib.check(self.clib.lib.mm_shield_qp(self._h, n, _ptr(G), _ptr(h), _ptr(rows), _ptr(u),
+                                                   _ptr(st), self._stream()), self._h)
+        return u, st
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.clib.lib.mm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_HIP = None
+
+
+def hip_library():
+    """Load libmm_hip.so once; fail loudly when it has not been built (no fallback)."""
+    global _HIP
+    if _HIP is None:
+        _HIP = abi.CLib(HIP_LIB)
+    return _HIP
+
+
+class VecMergeEnv(BatchedMergeEnv):
+    """The MI355X product path: HIP kernels over HBM-resident state."""
+
+    def __init__(self, E, N, env_id="merge-multi-agent-v1", config=None, device="cuda:0", **kw):
+        if not torch.cuda.is_available():
+            raise RuntimeError("VecMergeEnv needs a ROCm GPU (libmm_hip.so has no CPU fallback)")
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("VecMergeEnv runs on a GPU device, got %s" % device)
+        torch.cuda.set_device(dev)
+        super().__init__(hip_library(), E, N, env_id=env_id, config=config, device=dev, **kw)

@@ -1,0 +1,1191 @@
+/*
+ * mm_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * Plain-C, scalar, one-env-at-a-time restatement of the hot path of hkbharath/MARL-MASS
+ * (env.reset / env.step of merge-multi-agent-v0/-v1 + the HSS / MASS CBF shield), following the
+ * reference Python file by file; every function cites the reference lines it restates
+ * (paths relative to the reference root).  It exports the same C ABI as the HIP library
+ * (include/mm_abi.h) on HOST pointers.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
+ * and only as the checker / reported CPU baseline.  The product path never routes through it.
+ *
+ * Parity pin: checked against golden vectors generated from the reference itself
+ * (tools/gen_golden.py -> tests/golden/, test_oracle_golden.py).  The shield QP is solved by its
+ * exact KKT closed form; the reference's cvxopt 1.2.7 interior-point iterate is NOT available in
+ * this image, so the raw solver output is "parity unpinned" (see DESIGN.md).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (oracle/Makefile).  -ffp-contract=off
+ * keeps a*b+c as two roundings like CPython/numpy scalar arithmetic.
+ */
+#include "../include/mm_abi.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define PI 3.141592653589793 /* np.pi */
+
+/* ------------------------------------------------------------------ constants */
+#define VEH_LENGTH 5.0           /* kinematics.py:27 */
+#define VEH_WIDTH 2.0            /* kinematics.py:29 */
+#define MAX_SPEED 40.0           /* kinematics.py:33 */
+#define OBST_LENGTH 2.0          /* objects.py:18 */
+#define OBST_WIDTH 2.0           /* objects.py:19 */
+#define TAU_A 0.6                /* controller.py:23 */
+#define TAU_DS 0.2               /* controller.py:24 */
+#define LC_MAX_ACC 6.0           /* safe_controller.py:17 */
+#define LC_MIN_ACC (-12.5)       /* safe_controller.py:20 */
+#define PERCEPTION_DIST 180.0    /* safe_controller.py:21, abstract.py:41 */
+#define STOPPING_SPEED 1.6667    /* safe_controller.py:25 */
+#define LANE_WIDTH 4.0           /* lane.py:15 */
+#define CBF_ACC_LO (-12.5)       /* cbf.py:202 CBF_AV.ACCELERATION_RANGE */
+#define CBF_ACC_HI 6.0
+#define ADJ_BUFFER 2.0134        /* cbf.py:27 */
+
+/* lane table: merge_env_v1.py:222-248 (ends = [220, 100, 100, 1000], abstract.py:78) */
+static const double LANE_SX[6] = {0.0, 320.0, 320.0, 420.0, 0.0, 220.0};
+static const double LANE_SY[6] = {0.0, 0.0, 4.0, 0.0, 10.5, 7.25};
+static const double LANE_LEN[6] = {320.0, 100.0, 100.0, 1000.0, 220.0, 100.0};
+static const int LANE_FORBIDDEN[6] = {0, 0, 1, 0, 1, 1};
+#define SINE_AMP 3.25
+#define SINE_PULS (2 * PI / (2 * 100.0)) /* 2*np.pi / (2*ends[1]) */
+#define SINE_PHASE (PI / 2)
+#define OBST_X 420.0 /* lbc.position(ends[2], 0) */
+#define OBST_Y 4.0
+
+typedef struct {
+  double x, y, heading, speed, target_speed;
+  double act_steer, act_acc;   /* self.action */
+  double safe_steer, safe_acc; /* self.safe_action */
+  double g_vx;                 /* fg_params["g"]["vx"] */
+  double h1[4], h2[4];         /* state_hist[-1], [-2]: x, heading, vx, speed */
+  int lane, target_lane, speed_index, crashed, hl_action, flags, hist_len, kind;
+  double local_reward, regional_reward;
+  /* trace of the last shield call */
+  double qp_rows, qp_a, qp_h[4], qp_d;
+} Veh;
+
+typedef struct {
+  int n;
+  Veh v[MM_MAX_AGENTS];
+  int steps, time, n_merge, episode;
+} Env;
+
+struct MMHandle_ {
+  MMConfig cfg;
+  int E, N;
+  unsigned char *state;
+  MMStateLayout lay;
+  int64_t first_env;
+  double *metrics;
+  char err[256];
+};
+
+/* ------------------------------------------------------------------ utils.py */
+
+/* utils.py:40-41 wrap_to_pi with Python float % semantics (sign of the divisor) */
+static double py_mod(double a, double b) {
+  double m = fmod(a, b);
+  if (m != 0.0) {
+    if ((b < 0) != (m < 0)) m += b;
+  } else {
+    m = copysign(0.0, b);
+  }
+  return m;
+}
+static double wrap_to_pi(double x) { return py_mod(x + PI, 2 * PI) - PI; }
+
+/* utils.py:31-37 */
+static double not_zero(double x) {
+  const double eps = 1e-2;
+  if (fabs(x) > eps) return x;
+  else if (x > 0) return eps;
+  else return -eps;
+}
+static double clipd(double x, double a, double b) { return fmin(fmax(x, a), b); }
+
+/* utils.py:55-70 point_in_rotated_rectangle; NOTE rotates by +angle (upstream quirk, kept) */
+static int point_in_rotated_rectangle(double px, double py, double cx, double cy, double length,
+                                      double width, double angle) {
+  double c = cos(angle), s = sin(angle);
+  double dx = px - cx, dy = py - cy;
+  double ru0 = c * dx + (-s) * dy;
+  double ru1 = s * dx + c * dy;
+  return (-length / 2 <= ru0 && ru0 <= length / 2) && (-width / 2 <= ru1 && ru1 <= width / 2);
+}
+
+/* utils.py:102-121 has_corner_inside: 9 points of rect1 tested against rect2 */
+static int has_corner_inside(double c1x, double c1y, double l1, double w1, double a1, double c2x,
+                             double c2y, double l2, double w2, double a2) {
+  double lx = l1 / 2, wy = w1 / 2;
+  double pts[9][2] = {{0, 0},     {-lx, 0},  {lx, 0},    {0, -wy},  {0, wy},
+                      {-lx, -wy}, {-lx, wy}, {lx, -wy}, {lx, wy}};
+  double c = cos(a1), s = sin(a1);
+  for (int k = 0; k < 9; k++) {
+    double rx = c * pts[k][0] + (-s) * pts[k][1];
+    double ry = s * pts[k][0] + c * pts[k][1];
+    if (point_in_rotated_rectangle(c1x + rx, c1y + ry, c2x, c2y, l2, w2, a2)) return 1;
+  }
+  return 0;
+}
+/* utils.py:90-99 */
+static int rotated_rectangles_intersect(double c1x, double c1y, double l1, double w1, double a1,
+                                        double c2x, double c2y, double l2, double w2, double a2) {
+  return has_corner_inside(c1x, c1y, l1, w1, a1, c2x, c2y, l2, w2, a2) ||
+         has_corner_inside(c2x, c2y, l2, w2, a2, c1x, c1y, l1, w1, a1);
+}
+
+/* ------------------------------------------------------------------ road/lane.py */
+
+/* lane.py:164-168 (StraightLane) and :208-210 (SineLane); direction = (1, 0) for every lane */
+static void lane_local(int lane, double x, double y, double *s, double *r) {
+  double lon = x - LANE_SX[lane];
+  double lat = y - LANE_SY[lane];
+  if (lane == MM_LANE_KB0) lat = lat - SINE_AMP * sin(SINE_PULS * lon + SINE_PHASE);
+  *s = lon;
+  *r = lat;
+}
+/* lane.py:158-159, :204-206 */
+static double lane_heading_at(int lane, double s) {
+  if (lane == MM_LANE_KB0) return 0.0 + atan(SINE_AMP * SINE_PULS * cos(SINE_PULS * s + SINE_PHASE));
+  return 0.0;
+}
+/* lane.py:97-100 distance */
+static double lane_distance(int lane, double x, double y) {
+  double s, r;
+  lane_local(lane, x, y, &s, &r);
+  return fabs(r) + fmax(s - LANE_LEN[lane], 0) + fmax(0 - s, 0);
+}
+/* lane.py:102-108 distance_with_heading (heading_weight = 1) */
+static double lane_distance_with_heading(int lane, double x, double y, double heading) {
+  double s, r;
+  lane_local(lane, x, y, &s, &r);
+  double angle = fabs(wrap_to_pi(heading - lane_heading_at(lane, s)));
+  return fabs(r) + fmax(s - LANE_LEN[lane], 0) + fmax(0 - s, 0) + 1.0 * angle;
+}
+/* lane.py:61-76 on_lane (margin 0; longitudinal/lateral recomputed) */
+static int lane_on_lane(int lane, double x, double y) {
+  double s, r;
+  lane_local(lane, x, y, &s, &r);
+  return fabs(r) <= LANE_WIDTH / 2 + 0 && (-VEH_LENGTH <= s && s < LANE_LEN[lane] + VEH_LENGTH);
+}
+/* lane.py:78-90 is_reachable_from */
+static int lane_is_reachable_from(int lane, double x, double y) {
+  if (LANE_FORBIDDEN[lane]) return 0;
+  double s, r;
+  lane_local(lane, x, y, &s, &r);
+  return fabs(r) <= 2 * LANE_WIDTH && (0 <= s && s < LANE_LEN[lane] + VEH_LENGTH);
+}
+/* lane.py:92-95 after_end */
+static int lane_after_end(int lane, double x, double y) {
+  double s, r;
+  lane_local(lane, x, y, &s, &r);
+  return s > LANE_LEN[lane] - VEH_LENGTH / 2;
+}
+
+/* ------------------------------------------------------------------ road/road.py */
+
+/* road.py:51-65 get_closest_lane_index: first minimum in insertion order */
+static int closest_lane(double x, double y, double heading) {
+  int best = 0;
+  double bd = lane_distance_with_heading(0, x, y, heading);
+  for (int l = 1; l < 6; l++) {
+    double d = lane_distance_with_heading(l, x, y, heading);
+    if (d < bd) { bd = d; best = l; }
+  }
+  return best;
+}
+/* road.py:67-109 next_lane on the merge graph a->b->c->d, j->k->b (no route, one successor each) */
+static int next_lane(int lane, double x, double y) {
+  switch (lane) {
+    case MM_LANE_AB0: /* 1 lane -> 2 lanes: closest by lane.distance, first min wins */
+    case MM_LANE_KB0:
+      return lane_distance(MM_LANE_BC0, x, y) <= lane_distance(MM_LANE_BC1, x, y) ? MM_LANE_BC0
+                                                                                  : MM_LANE_BC1;
+    case MM_LANE_BC0:
+    case MM_LANE_BC1: return MM_LANE_CD0; /* 2 lanes -> 1 lane */
+    case MM_LANE_CD0: return MM_LANE_CD0; /* KeyError branch: end of network */
+    case MM_LANE_JK0: return MM_LANE_KB0; /* same lane count: keep id 0 */
+  }
+  return lane;
+}
+static int lane_road(int lane) { /* (from,to) pair id */
+  static const int r[6] = {0, 1, 1, 2, 3, 4};
+  return r[lane];
+}
+static int lane_id_in_road(int lane) { return lane == MM_LANE_BC1 ? 1 : 0; }
+
+/* ------------------------------------------------------------------ vehicle/controller.py */
+
+/* controller.py:327-337 speed_to_index (np.round = round-half-even = rint) */
+static int speed_to_index(double speed) {
+  double x = (speed - 10) / (30 - 10);
+  return (int)clipd(rint(x * (5 - 1)), 0, 5 - 1);
+}
+/* controller.py:313-325 */
+static double index_to_speed(int index) { return 10 + index * (30.0 - 10) / (5 - 1); }
+
+/* controller.py:136-144 follow_road */
+static void follow_road(Veh *v) {
+  if (lane_after_end(v->target_lane, v->x, v->y))
+    v->target_lane = next_lane(v->target_lane, v->x, v->y);
+}
+/* controller.py:146-187 steering_control */
+static double steering_control(const Veh *v, int target_lane) {
+  const double KP_HEADING = 1 / TAU_DS, KP_LATERAL = 1.0 / 3 * KP_HEADING;
+  const double PURSUIT_TAU = 0.5 * TAU_DS, MAX_STEER = PI / 3;
+  double s, r;
+  lane_local(target_lane, v->x, v->y, &s, &r);
+  double lane_next = s + v->speed * PURSUIT_TAU;
+  double lane_future_heading = lane_heading_at(target_lane, lane_next);
+  double lateral_speed_command = -KP_LATERAL * r;
+  double heading_command = asin(clipd(lateral_speed_command / not_zero(v->speed), -1, 1));
+  double heading_ref = lane_future_heading + clipd(heading_command, -PI / 4, PI / 4);
+  double heading_rate_command = KP_HEADING * wrap_to_pi(heading_ref - v->heading);
+  double steering_angle =
+      asin(clipd(VEH_LENGTH / 2 / not_zero(v->speed) * heading_rate_command, -1, 1));
+  return clipd(steering_angle, -MAX_STEER, MAX_STEER);
+}
+/* controller.py:189-197 */
+static double speed_control(const Veh *v, double target_speed) {
+  return (1 / TAU_A) * (target_speed - v->speed);
+}
+/* controller.py:90-134 ControlledVehicle.act; action: 0 LEFT 1 IDLE 2 RIGHT, -1 None */
+static void controlled_act(Veh *v, int action) {
+  follow_road(v);
+  if (action == 2 || action == 0) {
+    int road = lane_road(v->target_lane), id = lane_id_in_road(v->target_lane);
+    int nl = (road == 1) ? 2 : 1;
+    int nid = id + (action == 2 ? 1 : -1);
+    if (nid < 0) nid = 0;
+    if (nid > nl - 1) nid = nl - 1;
+    int cand = (road == 1) ? (nid == 1 ? MM_LANE_BC1 : MM_LANE_BC0) : v->target_lane;
+    if (lane_is_reachable_from(cand, v->x, v->y)) v->target_lane = cand;
+  }
+  double steer = steering_control(v, v->target_lane);
+  v->act_acc = speed_control(v, v->target_speed);
+  v->act_steer = clipd(steer, -PI / 3, PI / 3);
+}
+/* controller.py:293-311 MDPVehicle.act (+ safe_controller.py:63-66 hl_action record) */
+static void mdp_act(Veh *v, int action, int is_lc) {
+  if (is_lc && action >= 0) v->hl_action = action;
+  if (action == 3) v->speed_index = speed_to_index(v->speed) + 1;
+  else if (action == 4) v->speed_index = speed_to_index(v->speed) - 1;
+  else { controlled_act(v, action); return; }
+  v->speed_index = (int)clipd(v->speed_index, 0, 5 - 1);
+  v->target_speed = index_to_speed(v->speed_index);
+  controlled_act(v, -1);
+}
+/* controller.py:257-267 get_corner; dir 0 = "L", 1 = "R" */
+static void get_corner(const Veh *v, int dir, double *cx, double *cy) {
+  const double CORNER_LEN = sqrt((VEH_WIDTH / 2) * (VEH_WIDTH / 2) + (VEH_LENGTH / 2) * (VEH_LENGTH / 2)) + 0.0075;
+  const double CORNER_ALPHA = atan(VEH_WIDTH / VEH_LENGTH);
+  *cx = v->x + (CORNER_LEN * cos(CORNER_ALPHA + v->heading));
+  if (dir == 0) *cy = v->y - (CORNER_LEN * sin(CORNER_ALPHA + v->heading)) + 0.01;
+  else *cy = v->y - (CORNER_LEN * sin(-CORNER_ALPHA + v->heading)) + 0.01;
+}
+
+/* ------------------------------------------------------------------ safety/decentral_layer.py */
+
+/* decentral_layer.py:15-20 */
+static int is_same_lane(const Veh *v, int lane2) {
+  int nl = next_lane(v->lane, v->x, v->y);
+  return v->lane == lane2 || lane2 == nl;
+}
+/* decentral_layer.py:23-39 */
+static int is_adj_lane(const Veh *v, int lane2) {
+  int l1 = v->lane, nl = next_lane(v->lane, v->x, v->y);
+  if (lane_road(l1) == lane_road(lane2) && abs(lane_id_in_road(l1) - lane_id_in_road(lane2)) == 1)
+    return lane_id_in_road(l1) - lane_id_in_road(lane2);
+  else if (lane_road(nl) == lane_road(lane2) &&
+           abs(lane_id_in_road(nl) - lane_id_in_road(lane2)) == 1)
+    return lane_id_in_road(nl) - lane_id_in_road(lane2);
+  return 0;
+}
+/* kinematics.py:161-173 lane_distance_to in self.lane's frame */
+static double lane_distance_to(const Veh *self, const Veh *other) {
+  return (other->x - LANE_SX[self->lane]) - (self->x - LANE_SX[self->lane]);
+}
+/* decentral_layer.py:46-57 */
+static int is_approaching_same_lane(const Veh *ve, const Veh *vl) {
+  if (lane_distance_to(ve, vl) < 0) return 0;
+  double y_dist = vl->y - ve->y;
+  int dist_cond = fabs(y_dist) <= 3.5;
+  int heading_cond = (y_dist < 0) ? (vl->heading > 0.037) : (vl->heading < -0.037);
+  return dist_cond && heading_cond;
+}
+
+typedef struct { int present; double x, heading, vx, speed; } NState; /* dict subset the shield reads */
+
+/* decentral_layer.py:60-77 simplified_control */
+static void simplified_control(const NState *s, double acc, double steer, double vl, double dt,
+                               double *v_out, double *dpsi_out) {
+  if (!s->present) { *v_out = 0; *dpsi_out = 0; return; }
+  double speed = s->speed;
+  double v = s->vx + acc * dt;
+  v = v > 0 ? v : 0; /* max(0, v) */
+  double beta = atan(0.5 * tan(steer));
+  *dpsi_out = (speed / vl * sin(beta)) + s->heading;
+  *v_out = v;
+}
+
+/* road.py:257-267 close_vehicles_to: indices of <= count nearest others, sorted by |lane distance| (stable) */
+static int close_vehicles_to(const Env *e, int i, double distance, int count, int *out) {
+  int idx[MM_MAX_AGENTS], m = 0;
+  double key[MM_MAX_AGENTS];
+  const Veh *me = &e->v[i];
+  for (int j = 0; j < e->n; j++) {
+    if (j == i) continue;
+    double dx = e->v[j].x - me->x, dy = e->v[j].y - me->y;
+    if (sqrt(dx * dx + dy * dy) < distance) {
+      idx[m] = j;
+      key[m] = fabs(lane_distance_to(me, &e->v[j]));
+      m++;
+    }
+  }
+  for (int a = 1; a < m; a++) { /* stable insertion sort */
+    int ja = idx[a]; double ka = key[a]; int b = a - 1;
+    while (b >= 0 && key[b] > ka) { idx[b + 1] = idx[b]; key[b + 1] = key[b]; b--; }
+    idx[b + 1] = ja; key[b + 1] = ka;
+  }
+  if (m > count) m = count;
+  for (int a = 0; a < m; a++) out[a] = idx[a];
+  return m;
+}
+
+/*
+ * safety_layer -> safe_action_hss / safe_action_mass (decentral_layer.py:290-518, :521-764,
+ * :767-817) with multi_agent_state (:85-257) and the CBF rows of cbf.py:262-430.  The QP
+ * (cbf.py:134, cvxopt) is solved by its exact KKT closed form.
+ * Returns 0, or MM_ERR_QP_BOUNDS when check_bounds (cbf.py:87-96) would raise.
+ */
+static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *safe_acc,
+                        double *safe_steer) {
+  Veh *veh = &e->v[i];
+  const int mass = cfg->shield == MM_SHIELD_MASS;
+  const double eta = cfg->cbf_eta, TAU = cfg->cbf_tau;
+  double v_min = veh->speed + LC_MIN_ACC * dt;
+  if (mass) v_min = v_min > 0 ? v_min : 0; /* max(0, v_min), :798 */
+  double v_max = veh->speed + LC_MAX_ACC * dt;
+
+  /* s_e = vehicle.to_dict() (+ speed), vx floored at 1 (:307-309) */
+  NState s_e = {1, veh->x, veh->heading, veh->speed * cos(veh->heading), veh->speed};
+  s_e.vx = s_e.vx > 1 ? s_e.vx : 1;
+  double sf_ol[2] = {s_e.x + PERCEPTION_DIST + 1, 0.0};
+  double sf_oa[2] = {s_e.x + PERCEPTION_DIST + 1, 0.0};
+  double sf_oar[2] = {s_e.x - PERCEPTION_DIST - 1, 0.0};
+
+  /* ---- multi_agent_state (:85-257) */
+  NState s_ol = {0}, s_oa = {0}, s_oar = {0};
+  double a_ol_acc = 0, a_ol_steer = 0, a_oa_acc = 0, a_oa_steer = 0;
+  double gp_ol = 0, gp_oa = 0;
+  int constrain_adj = 0;
+  int near[MM_MAX_AGENTS];
+  int m = close_vehicles_to(e, i, PERCEPTION_DIST, 5, near);
+  for (int k = 0; k < m; k++) {
+    const Veh *o = &e->v[near[k]];
+    int v_a = is_adj_lane(veh, o->lane);
+    int a_v = is_adj_lane(o, veh->lane);
+    int appr = is_approaching_same_lane(veh, o);
+    double ld = lane_distance_to(veh, o);
+    if (!appr && (v_a || a_v)) {
+      if (!s_oar.present && ld < 0) {
+        s_oar.present = 1; /* veh.to_dict(): current state */
+        s_oar.x = o->x; s_oar.heading = o->heading;
+        s_oar.vx = o->speed * cos(o->heading); s_oar.speed = o->speed;
+      } else if (!s_oa.present && ld >= 0) {
+        s_oa.present = 1; /* veh.state_hist[-2] */
+        s_oa.x = o->h2[0]; s_oa.heading = o->h2[1]; s_oa.vx = o->h2[2]; s_oa.speed = o->h2[3];
+        if (mass) {
+          a_oa_acc = o->safe_acc; a_oa_steer = o->safe_steer; gp_oa = o->g_vx;
+          /* :138-160: the corner test always overrides the collaborate_adj expression */
+          double cx, cy;
+          if (v_a == -1 || a_v == 1) get_corner(o, 0, &cx, &cy);
+          else get_corner(o, 1, &cx, &cy);
+          constrain_adj = !lane_on_lane(o->lane, cx, cy);
+        }
+      }
+    } else if (!s_ol.present && (is_same_lane(veh, o->lane) || appr) && ld > 0) {
+      s_ol.present = 1;
+      s_ol.x = o->h2[0]; s_ol.heading = o->h2[1]; s_ol.vx = o->h2[2]; s_ol.speed = o->h2[3];
+      if (mass) { a_ol_acc = o->safe_acc; a_ol_steer = o->safe_steer; gp_ol = o->g_vx; }
+    }
+  }
+  /* obstacles (:213-246): one Obstacle at (420, 4) */
+  if (!(veh->x > OBST_X)) {
+    if ((!s_ol.present || OBST_X <= s_ol.x) && fabs(OBST_Y - veh->y) <= 2) {
+      s_ol.present = 1; s_ol.x = OBST_X; s_ol.heading = 0; s_ol.vx = 0.0;
+      s_ol.speed = 0.0 / cos(0.0); /* "cos_h" branch of simplified_control */
+      if (mass) { a_ol_acc = 0; a_ol_steer = 0; gp_ol = 0; }
+    }
+    double ady = fabs(OBST_Y - veh->y);
+    if ((!s_oa.present || OBST_X <= s_oa.x) && (2 < ady && ady <= 4)) {
+      s_oa.present = 1; s_oa.x = OBST_X; s_oa.heading = 0; s_oa.vx = 0.0;
+      s_oa.speed = 0.0 / cos(0.0);
+      if (mass) { a_oa_acc = 0; a_oa_steer = 0; gp_oa = 0; constrain_adj = 0; }
+    }
+  }
+  if (s_oa.present) { sf_oa[0] = s_oa.x; sf_oa[1] = s_oa.heading; }
+  if (s_ol.present) { sf_ol[0] = s_ol.x; sf_ol[1] = s_ol.heading; }
+  if (s_oar.present) { sf_oar[0] = s_oar.x; sf_oar[1] = s_oar.heading; }
+
+  /* ---- g (diagonal 8x8 after the transpose, :392-442 / :626-676), x, f = x */
+  double g[8];
+  g[0] = veh->g_vx * dt; g[1] = 1 * dt;
+  g[2] = mass ? gp_ol * dt : 1 * dt; g[3] = 1 * dt;
+  g[4] = mass ? gp_oa * dt : 1 * dt; g[5] = 1 * dt;
+  g[6] = 1 * dt; g[7] = 1 * dt;
+  double x[8] = {s_e.x, s_e.heading, sf_ol[0], sf_ol[1], sf_oa[0], sf_oa[1], sf_oar[0], sf_oar[1]};
+
+  /* ---- safe distances (:448-470) */
+  double sv_oar = s_oar.present ? s_oar.vx : 0;
+  sv_oar = sv_oar + CBF_ACC_HI * dt;
+  sv_oar = sv_oar > 1 ? sv_oar : 1;
+  double buffer = (CBF_ACC_HI + 0.1) * dt * TAU;
+  double sd0 = s_e.vx * TAU + VEH_LENGTH + buffer;
+  double sd1 = sd0;
+  double sd2 = sv_oar * TAU + VEH_LENGTH + buffer;
+
+  /* ---- predicted inputs (:473-488 HSS worst case, :706-714 MASS decided actions) */
+  double u[8];
+  simplified_control(&s_e, veh->act_acc, veh->act_steer, VEH_LENGTH, dt, &u[0], &u[1]);
+  if (mass) {
+    simplified_control(&s_ol, a_ol_acc, a_ol_steer, VEH_LENGTH, dt, &u[2], &u[3]);
+    simplified_control(&s_oa, a_oa_acc, a_oa_steer, VEH_LENGTH, dt, &u[4], &u[5]);
+  } else {
+    simplified_control(&s_ol, CBF_ACC_LO, 0, VEH_LENGTH, dt, &u[2], &u[3]);
+    simplified_control(&s_oa, CBF_ACC_LO, 0, VEH_LENGTH, dt, &u[4], &u[5]);
+  }
+  simplified_control(&s_oar, CBF_ACC_HI, 0, VEH_LENGTH, dt, &u[6], &u[7]);
+
+  /* ---- control_barrier (cbf.py:110-161): define_pq, get_G, get_h */
+  double q_lon = -VEH_LENGTH - sd0;
+  double q_lona = -VEH_LENGTH - sd1;
+  double q_lonr = -VEH_LENGTH - sd2;
+  if (mass && constrain_adj) q_lona = -VEH_LENGTH - sd1 - ADJ_BUFFER; /* cbf.py:380-384 */
+  double a = g[0]; /* G[0] = [g_e.vx*dt, 0, -1] */
+  double px_lon = x[2] - x[0], px_lona = x[4] - x[0], px_lonr = x[0] - x[6];
+  double h0 = px_lon + (eta - 1) * px_lon + eta * q_lon + (-(g[0] * u[0]) + g[2] * u[2]);
+  double h1 = v_max - u[0];
+  double h2 = -v_min + u[0];
+  int rows = 3;
+  double h3 = NAN, hc = h0;
+  if (mass && constrain_adj) {
+    h3 = px_lona + (eta - 1) * px_lona + eta * q_lona + (-(g[0] * u[0]) + g[4] * u[4]);
+    rows = 4;
+    hc = h3 < h0 ? h3 : h0;
+  }
+  /* exact KKT solution of min 1/2(d^2 + e^2 + 1e18 s^2): see tools/refshim/cvxopt */
+  double hi = h1, lo = -h2, d;
+  if (a > 0) d = fmin(0.0, hc / a);
+  else if (a < 0) d = fmax(0.0, hc / a);
+  else d = 0.0;
+  d = fmin(fmax(d, lo), hi);
+  double u_safe0 = u[0] + d, u_safe1;
+  veh->qp_rows = rows; veh->qp_a = a; veh->qp_h[0] = h0; veh->qp_h[1] = h1; veh->qp_h[2] = h2;
+  veh->qp_h[3] = h3; veh->qp_d = d;
+  int rc = 0;
+  if (u_safe0 - 0.001 > v_max || u_safe0 + 0.001 < v_min) rc = MM_ERR_QP_BOUNDS; /* cbf.py:87-96 */
+
+  u_safe1 = veh->act_steer; /* :493 / :721 lateral control is not constrained */
+  double um[8] = {u_safe0, u_safe1, u[2], u[3], u[4], u[5], u[6], u[7]}; /* u_safe_ma */
+  int flags = veh->flags & MM_FLAG_COLLABORATE_ADJ;
+  if (constrain_adj) flags |= MM_FLAG_IS_COLLABORATING;
+  flags |= MM_FLAG_IS_LC_SAFE;
+
+  /* is_lc_allowed (cbf.py:324-339) */
+  double hls_lona = px_lona + q_lona;
+  double hlds_lona = px_lona + ((-g[0]) * um[0] + g[4] * um[4]) + q_lona;
+  double hls_lonr = px_lonr + q_lonr;
+  double hlds_lonr = px_lonr + (g[0] * um[0] + (-g[6]) * um[6]) + q_lonr;
+  int lc_allowed = ((hls_lona >= 0) && (hlds_lona + (eta - 1) * hls_lona) >= 0) &&
+                   ((hls_lonr >= 0) && (hlds_lonr + (eta - 1) * hls_lonr) >= 0);
+  if (!mass) {
+    if (!lc_allowed) { /* :501-506 */
+      veh->target_lane = veh->lane;
+      u_safe1 = steering_control(veh, veh->target_lane);
+      flags &= ~MM_FLAG_IS_LC_SAFE;
+    }
+  } else {
+    double cx, cy;
+    int can_abort_lc = 1; /* :728-736: both front corners still on the current lane */
+    get_corner(veh, 0, &cx, &cy);
+    can_abort_lc = can_abort_lc && lane_on_lane(veh->lane, cx, cy);
+    get_corner(veh, 1, &cx, &cy);
+    can_abort_lc = can_abort_lc && lane_on_lane(veh->lane, cx, cy);
+    if (can_abort_lc && !lc_allowed) { /* :739-744 */
+      veh->target_lane = veh->lane;
+      u_safe1 = steering_control(veh, veh->target_lane);
+      flags &= ~MM_FLAG_IS_LC_SAFE;
+    } else if ((veh->hl_action == 2 || veh->hl_action == 0) && veh->speed < STOPPING_SPEED) {
+      u_safe0 = u[0]; /* :746-750 */
+    }
+    /* can_collaborate_adj (cbf.py:424-430) on u_safe_ma (copied before the edits above) */
+    double inv = hlds_lona + (eta - 1) * hls_lona;
+    if (inv >= -1e-6) flags |= MM_FLAG_COLLABORATE_ADJ; else flags &= ~MM_FLAG_COLLABORATE_ADJ;
+  }
+  veh->flags = flags;
+  *safe_acc = (u_safe0 - s_e.vx) / dt; /* derived_acceleration :80-82 */
+  *safe_steer = u_safe1;
+  return rc;
+}
+
+/* ------------------------------------------------------------------ vehicle step */
+
+/* kinematics.py:143-152 (+ safe_controller.py:100-104 for MDPLCVehicle) */
+static void clip_actions(Veh *v, int is_lc) {
+  if (v->crashed) { v->act_steer = 0; v->act_acc = -1.0 * v->speed; }
+  if (v->speed > MAX_SPEED) v->act_acc = fmin(v->act_acc, 1.0 * (MAX_SPEED - v->speed));
+  else if (v->speed < -MAX_SPEED) v->act_acc = fmax(v->act_acc, 1.0 * (MAX_SPEED - v->speed));
+  if (is_lc) v->act_acc = clipd(v->act_acc, LC_MIN_ACC, LC_MAX_ACC);
+}
+
+/* kinematics.py:122-141 Vehicle.step / safe_controller.py:106-185 MDPLCVehicle.step ("steer") */
+static int vehicle_step(const MMConfig *cfg, Env *e, int i, double dt) {
+  Veh *v = &e->v[i];
+  const int is_lc = cfg->env_kind == MM_ENV_V1;
+  int rc = 0;
+  clip_actions(v, is_lc);
+  double steer = v->act_steer, acc = v->act_acc;
+  v->qp_rows = 0; v->qp_a = NAN; v->qp_d = NAN;
+  v->qp_h[0] = v->qp_h[1] = v->qp_h[2] = v->qp_h[3] = NAN;
+  if (is_lc && cfg->shield != MM_SHIELD_NONE && v->hist_len >= 2) /* gate :232-239 */
+    rc = safety_layer(cfg, e, i, dt, &acc, &steer);
+  if (is_lc) { v->safe_steer = steer; v->safe_acc = acc; }
+  double beta = atan(1.0 / 2 * tan(steer));
+  double vx = v->speed * cos(v->heading + beta);
+  double vy = v->speed * sin(v->heading + beta);
+  v->x += vx * dt;
+  v->y += vy * dt;
+  v->heading += v->speed * sin(beta) / (VEH_LENGTH / 2) * dt;
+  v->speed += acc * dt;
+  v->speed = v->speed > 0 ? v->speed : 0; /* max(0, speed) */
+  if (is_lc) v->g_vx = cos(v->heading + beta);
+  v->lane = closest_lane(v->x, v->y, v->heading); /* on_state_update kinematics.py:154-159 */
+  if (is_lc) { /* log_step: state_hist.append(to_dict()) safe_controller.py:187-201 */
+    memcpy(v->h2, v->h1, sizeof v->h1);
+    v->h1[0] = v->x; v->h1[1] = v->heading; v->h1[2] = v->speed * cos(v->heading);
+    v->h1[3] = v->speed;
+    if (v->hist_len < 2) v->hist_len++;
+  }
+  return rc;
+}
+
+/* kinematics.py:202-209 _is_colliding */
+static int is_colliding(const Veh *a, double ox, double oy, double ol, double ow, double oh) {
+  double dx = ox - a->x, dy = oy - a->y;
+  if (sqrt(dx * dx + dy * dy) > VEH_LENGTH) return 0;
+  return rotated_rectangles_intersect(a->x, a->y, 0.9 * VEH_LENGTH, 0.9 * VEH_WIDTH, a->heading,
+                                      ox, oy, 0.9 * ol, 0.9 * ow, oh);
+}
+
+static void sort_by_x_desc(const Env *e, int *order) { /* sorted(key=x, reverse=True): stable */
+  for (int i = 0; i < e->n; i++) order[i] = i;
+  for (int a = 1; a < e->n; a++) {
+    int ja = order[a], b = a - 1;
+    while (b >= 0 && e->v[order[b]].x < e->v[ja].x) { order[b + 1] = order[b]; b--; }
+    order[b + 1] = ja;
+  }
+}
+
+/* merge_env_v1.py:168-172 */
+static int is_terminal(const MMConfig *cfg, const Env *e) {
+  int any_crashed = 0, any_neg = 0;
+  for (int i = 0; i < e->n; i++) { any_crashed |= e->v[i].crashed; any_neg |= e->v[i].x < 0; }
+  return any_crashed || e->steps >= cfg->duration * cfg->policy_frequency || any_neg;
+}
+
+/* abstract.py:512-532 _simulate with road.act / road.step (road.py:269-292) */
+static int simulate(const MMConfig *cfg, Env *e, const int32_t *actions, double *trace, int64_t A,
+                    int64_t base) {
+  const int is_lc = cfg->env_kind == MM_ENV_V1;
+  const int nsub = cfg->simulation_frequency / cfg->policy_frequency;
+  const double dt = 1.0 / cfg->simulation_frequency;
+  int rc = 0, order[MM_MAX_AGENTS];
+  for (int k = 0; k < nsub; k++) {
+    if (e->time % nsub == 0) /* action_type.act(action): action.py:226-231 */
+      for (int i = 0; i < e->n; i++) mdp_act(&e->v[i], actions[i], is_lc);
+    sort_by_x_desc(e, order); /* road.act */
+    for (int r = 0; r < e->n; r++) mdp_act(&e->v[order[r]], -1, is_lc);
+    sort_by_x_desc(e, order); /* road.step */
+    for (int r = 0; r < e->n; r++) {
+      int rr = vehicle_step(cfg, e, order[r], dt);
+      if (rr) rc = rr;
+    }
+    for (int i = 0; i < e->n; i++) { /* collision loop road.py:288-292, kinematics.py:175-200 */
+      Veh *v = &e->v[i];
+      for (int j = 0; j < e->n; j++) {
+        Veh *o = &e->v[j];
+        if (v->crashed || j == i) continue;
+        if (is_colliding(v, o->x, o->y, VEH_LENGTH, VEH_WIDTH, o->heading)) {
+          double s = fabs(v->speed) <= fabs(o->speed) ? v->speed : o->speed;
+          v->speed = o->speed = s;
+          v->crashed = o->crashed = 1;
+        }
+      }
+      if (!v->crashed && is_colliding(v, OBST_X, OBST_Y, OBST_LENGTH, OBST_WIDTH, 0.0)) {
+        v->speed = fabs(v->speed) <= 0 ? v->speed : 0.0;
+        v->crashed = 1;
+      }
+    }
+    e->time += 1;
+    if (trace) {
+      for (int i = 0; i < e->n; i++) {
+        const Veh *v = &e->v[i];
+        double *t = trace + (int64_t)k * MM_T_COUNT * A + base + i;
+        t[MM_T_X * A] = v->x; t[MM_T_Y * A] = v->y; t[MM_T_HEADING * A] = v->heading;
+        t[MM_T_SPEED * A] = v->speed; t[MM_T_ACT_STEER * A] = v->act_steer;
+        t[MM_T_ACT_ACC * A] = v->act_acc;
+        t[MM_T_SAFE_STEER * A] = is_lc ? v->safe_steer : v->act_steer;
+        t[MM_T_SAFE_ACC * A] = is_lc ? v->safe_acc : v->act_acc;
+        t[MM_T_LANE * A] = v->lane; t[MM_T_TARGET_LANE * A] = v->target_lane;
+        t[MM_T_CRASHED * A] = v->crashed; t[MM_T_FLAGS * A] = v->flags;
+        t[MM_T_QP_ROWS * A] = v->qp_rows; t[MM_T_QP_A * A] = v->qp_a;
+        t[MM_T_QP_H0 * A] = v->qp_h[0]; t[MM_T_QP_H1 * A] = v->qp_h[1];
+        t[MM_T_QP_H2 * A] = v->qp_h[2]; t[MM_T_QP_H3 * A] = v->qp_h[3];
+        t[MM_T_QP_D * A] = v->qp_d;
+      }
+    }
+    if (is_terminal(cfg, e)) break;
+  }
+  return rc;
+}
+
+/* ------------------------------------------------------------------ observation.py */
+
+/* observation.py:195-226 (Kinematics) / :244-273 (KinematicLC) for observer i; out[5*F] */
+static void observe_agent(const MMConfig *cfg, const Env *e, int i, double *out) {
+  const int F = cfg->env_kind == MM_ENV_V1 ? 6 : 5;
+  const Veh *me = &e->v[i];
+  for (int k = 0; k < 5 * F; k++) out[k] = 0.0;
+  double evx = me->speed * cos(me->heading), evy = me->speed * sin(me->heading);
+  double rows[5][6];
+  int nrows = 1;
+  rows[0][0] = 1; rows[0][1] = me->x; rows[0][2] = me->y; rows[0][3] = evx; rows[0][4] = evy;
+  rows[0][5] = me->heading;
+  int near[MM_MAX_AGENTS];
+  int m = close_vehicles_to(e, i, PERCEPTION_DIST, 5 - 1, near);
+  for (int k = 0; k < m; k++) {
+    const Veh *o = &e->v[near[k]];
+    double ovx = o->speed * cos(o->heading), ovy = o->speed * sin(o->heading);
+    rows[nrows][0] = 1; rows[nrows][1] = o->x - me->x; rows[nrows][2] = o->y - me->y;
+    rows[nrows][3] = ovx - evx; rows[nrows][4] = ovy - evy; rows[nrows][5] = o->heading;
+    nrows++;
+  }
+  /* normalize_obs :181-193 with utils.lmap :16-18; ranges :171-176, :238-239; clip=False */
+  const double lo[6] = {0, -5.0 * 30, -12, -1.5 * 30, -1.5 * 30, -PI / 2};
+  const double hi[6] = {0, 5.0 * 30, 12, 1.5 * 30, 1.5 * 30, PI / 2};
+  for (int r = 0; r < nrows; r++) {
+    out[r * F + 0] = rows[r][0];
+    for (int f = 1; f < F; f++)
+      out[r * F + f] = -1 + (rows[r][f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f]);
+  }
+}
+
+/* abstract.py:219-240 + the row-aliasing of :202,:475 (mask = OR over agents when masking) */
+static void action_mask(const MMConfig *cfg, const Env *e, uint8_t *out /* [n][5] */) {
+  uint8_t m[5] = {1, 1, 1, 1, 1};
+  if (cfg->action_masking) {
+    memset(m, 0, 5);
+    for (int i = 0; i < e->n; i++) {
+      const Veh *v = &e->v[i];
+      m[1] = 1;
+      if (v->lane == MM_LANE_BC1 && lane_is_reachable_from(MM_LANE_BC0, v->x, v->y)) m[0] = 1;
+      if (v->lane == MM_LANE_BC0 && lane_is_reachable_from(MM_LANE_BC1, v->x, v->y)) m[2] = 1;
+      if (v->speed_index < 5 - 1) m[3] = 1;
+      if (v->speed_index > 0) m[4] = 1;
+    }
+  }
+  for (int i = 0; i < e->n; i++) memcpy(out + 5 * i, m, 5);
+}
+
+/* ------------------------------------------------------------------ rewards / info */
+
+/* abstract.py:620-635 */
+static double compute_headway_distance(const Env *e, int i) {
+  const Veh *veh = &e->v[i];
+  double hd = 60;
+  int nl = next_lane(veh->lane, veh->x, veh->y);
+  for (int j = 0; j < e->n; j++) {
+    const Veh *v = &e->v[j];
+    if (v->lane == veh->lane && v->x > veh->x) {
+      double d = v->x - veh->x;
+      if (d < hd) hd = d;
+    }
+    if (veh->lane != MM_LANE_BC1 && v->lane == nl && v->x > veh->x) {
+      double d = v->x - veh->x;
+      if (d < hd) hd = d;
+    }
+  }
+  return hd;
+}
+/* merge_env_v1.py:64-89 (v1 "default" agent_reward delegates here, :446-447) */
+static double agent_reward(const MMConfig *cfg, const Env *e, int i) {
+  const Veh *v = &e->v[i];
+  double scaled_speed = 0 + (v->speed - cfg->reward_speed_lo) * (1 - 0) /
+                                (cfg->reward_speed_hi - cfg->reward_speed_lo);
+  double merging = 0;
+  if (v->lane == MM_LANE_BC1) merging = -exp(-pow(v->x - 420, 2) / (10 * 100));
+  double hd = compute_headway_distance(e, i);
+  double hc = v->speed > 0 ? log(hd / (cfg->headway_time * v->speed)) : 0;
+  return cfg->collision_reward * (-1 * v->crashed) + (cfg->high_speed_reward * clipd(scaled_speed, 0, 1)) +
+         cfg->merging_lane_cost * merging + cfg->headway_cost * (hc < 0 ? hc : 0);
+}
+/* road.py:294-350 surrounding_vehicles with the hard-coded lane cases; returns front/rear index or -1 */
+static void surrounding_vehicles(const Env *e, int i, int lane_index, int *front, int *rear) {
+  static const uint8_t allow[6] = {
+      /* ab0 */ (1 << MM_LANE_AB0) | (1 << MM_LANE_BC0),
+      /* bc0 */ (1 << MM_LANE_AB0) | (1 << MM_LANE_BC0) | (1 << MM_LANE_CD0),
+      /* bc1 */ (1 << MM_LANE_KB0) | (1 << MM_LANE_BC1),
+      /* cd0 */ (1 << MM_LANE_BC0) | (1 << MM_LANE_CD0),
+      /* jk0 */ (1 << MM_LANE_JK0) | (1 << MM_LANE_KB0),
+      /* kb0 */ (1 << MM_LANE_JK0) | (1 << MM_LANE_KB0) | (1 << MM_LANE_BC1)};
+  double s = e->v[i].x, s_front = 0, s_rear = 0;
+  *front = *rear = -1;
+  for (int j = 0; j < e->n; j++) {
+    if (j == i) continue;
+    if (!((allow[lane_index] >> e->v[j].lane) & 1)) continue;
+    double s_v = e->v[j].x;
+    if (s <= s_v && (*front < 0 || s_v <= s_front)) { s_front = s_v; *front = j; }
+    if (s_v < s && (*rear < 0 || s_v > s_rear)) { s_rear = s_v; *rear = j; }
+  }
+}
+/* merge_env_v1.py:91-124 */
+static void regional_reward(Env *e) {
+  for (int i = 0; i < e->n; i++) {
+    Veh *v = &e->v[i];
+    int fl = -1, rl = -1, fr = -1, rr = -1;
+    if (v->lane == MM_LANE_AB0 || v->lane == MM_LANE_BC0 || v->lane == MM_LANE_CD0) {
+      surrounding_vehicles(e, i, v->lane, &fl, &rl);
+      if (v->lane == MM_LANE_BC0) surrounding_vehicles(e, i, MM_LANE_BC1, &fr, &rr);
+      else if (v->lane == MM_LANE_AB0 && v->x > 220) surrounding_vehicles(e, i, MM_LANE_KB0, &fr, &rr);
+    } else {
+      surrounding_vehicles(e, i, v->lane, &fr, &rr);
+      if (v->lane == MM_LANE_BC1) surrounding_vehicles(e, i, MM_LANE_BC0, &fl, &rl);
+      else if (v->lane == MM_LANE_KB0) surrounding_vehicles(e, i, MM_LANE_AB0, &fl, &rl);
+    }
+    int list[5] = {fl, fr, i, rl, rr};
+    double sum = 0; int cnt = 0;
+    for (int k = 0; k < 5; k++)
+      if (list[k] >= 0) { sum += e->v[list[k]].local_reward; cnt++; }
+    v->regional_reward = sum / cnt;
+  }
+}
+/* merge_env_v1.py:373-386 */
+static double min_time_headway(const Env *e) {
+  double mh = INFINITY;
+  for (int i = 0; i < e->n; i++) {
+    const Veh *v = &e->v[i];
+    double hd = compute_headway_distance(e, i);
+    if (fabs(OBST_Y - v->y) <= 2 && OBST_X > v->x) {
+      double d = OBST_X - v->x;
+      if (d < hd) hd = d;
+    }
+    hd = hd - VEH_LENGTH;
+    double vx = v->speed * cos(v->heading);
+    double th = hd / (vx > 1 ? vx : 1);
+    if (th < mh) mh = th;
+  }
+  return mh;
+}
+
+/* ------------------------------------------------------------------ reset */
+
+/* Philox4x32-10 (Salmon et al. 2011); the device reset kernel implements the same stream. */
+static void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                       uint32_t k1, uint32_t out[4]) {
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static uint32_t rng_u32(uint64_t seed, uint32_t episode, uint32_t t) {
+  uint32_t o[4];
+  philox4x32(t >> 2, episode, 0u, 0x4D4D5253u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  return o[t & 3];
+}
+static double rng_f64(uint64_t seed, uint32_t episode, uint32_t t) { /* 53-bit, like numpy's rk_double */
+  uint32_t a = rng_u32(seed, episode, t) >> 5, b = rng_u32(seed, episode, t + 1) >> 6;
+  return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+/* Vehicle/ControlledVehicle/MDPVehicle/MDPLCVehicle.__init__ from (x, y, heading, speed):
+ * kinematics.py:36-53, controller.py:35-50,277-291, safe_controller.py:27-61 */
+static void init_vehicle(Veh *v) {
+  v->lane = closest_lane(v->x, v->y, v->heading);
+  v->target_lane = v->lane;
+  v->target_speed = v->speed;
+  v->speed_index = speed_to_index(v->target_speed);
+  v->target_speed = index_to_speed(v->speed_index);
+  v->act_steer = v->act_acc = 0;
+  v->safe_steer = v->safe_acc = 0;
+  v->g_vx = NAN; /* fg_params = None */
+  memset(v->h1, 0, sizeof v->h1);
+  memset(v->h2, 0, sizeof v->h2);
+  v->crashed = 0; v->hl_action = MM_HL_NONE; v->flags = 0; v->hist_len = 0; v->kind = 1;
+  v->local_reward = v->regional_reward = 0;
+}
+
+/* merge_env_v1.py:265-364 _make_vehicles for N CAVs / 0 HDVs with the device RNG stream
+ * (draw plan documented in DESIGN.md "Device reset"): N/2 on ab0 first, the rest on jk0. */
+static void spawn_env(Env *e, int N, uint64_t seed, uint32_t episode) {
+  int slots_s[6] = {10, 60, 110, 160, 210, 260}, slots_m[6] = {5, 55, 105, 155, 205, 255};
+  int n_s = (N != 1) ? N / 2 : (int)(rng_u32(seed, episode, 0) & 1u);
+  int n_m = N - n_s;
+  for (int i = 0; i < n_s && i < 6; i++) { /* choice(replace=False) as a partial Fisher-Yates */
+    int j = i + (int)(((uint64_t)rng_u32(seed, episode, (uint32_t)i) * (uint32_t)(6 - i)) >> 32);
+    int t = slots_s[i]; slots_s[i] = slots_s[j]; slots_s[j] = t;
+  }
+  for (int i = 0; i < n_m && i < 6; i++) {
+    int j = i + (int)(((uint64_t)rng_u32(seed, episode, (uint32_t)(6 + i)) * (uint32_t)(6 - i)) >> 32);
+    int t = slots_m[i]; slots_m[i] = slots_m[j]; slots_m[j] = t;
+  }
+  e->n = N;
+  for (int k = 0; k < N; k++) {
+    Veh *v = &e->v[k];
+    double speed = rng_f64(seed, episode, 12u + 4u * k) * 2 + 25;
+    double noise = rng_f64(seed, episode, 12u + 4u * k + 2u) * 8 - 4;
+    if (k < n_s) { v->x = slots_s[k] + noise; v->y = 0.0; }
+    else { v->x = slots_m[k - n_s] + noise; v->y = 10.5; }
+    v->heading = 0; v->speed = speed;
+    init_vehicle(v);
+  }
+  e->steps = e->time = 0;
+  e->n_merge = n_m;
+}
+
+/* ------------------------------------------------------------------ SoA <-> Env */
+
+static void load_env(const struct MMHandle_ *h, int64_t e_idx, Env *e) {
+  const int64_t A = (int64_t)h->E * h->N, base = e_idx * h->N;
+  const double *F = (const double *)(h->state + h->lay.f64_offset);
+  const uint8_t *B = h->state + h->lay.u8_offset;
+  const int32_t *I = (const int32_t *)(h->state + h->lay.env_offset);
+  e->n = 0;
+  for (int a = 0; a < h->N; a++) {
+    int64_t i = base + a;
+    if (B[MM_B_KIND * A + i] == 0) continue;
+    Veh *v = &e->v[e->n++];
+    memset(v, 0, sizeof *v);
+    v->x = F[MM_F_X * A + i]; v->y = F[MM_F_Y * A + i]; v->heading = F[MM_F_HEADING * A + i];
+    v->speed = F[MM_F_SPEED * A + i]; v->target_speed = F[MM_F_TARGET_SPEED * A + i];
+    v->safe_steer = F[MM_F_SAFE_STEER * A + i]; v->safe_acc = F[MM_F_SAFE_ACC * A + i];
+    v->g_vx = F[MM_F_G_VX * A + i];
+    for (int k = 0; k < 4; k++) { v->h1[k] = F[(MM_F_H1_X + k) * A + i]; v->h2[k] = F[(MM_F_H2_X + k) * A + i]; }
+    v->lane = B[MM_B_LANE * A + i]; v->target_lane = B[MM_B_TARGET_LANE * A + i];
+    v->speed_index = B[MM_B_SPEED_INDEX * A + i]; v->crashed = B[MM_B_CRASHED * A + i];
+    v->hl_action = B[MM_B_HL_ACTION * A + i]; v->flags = B[MM_B_FLAGS * A + i];
+    v->hist_len = B[MM_B_HIST_LEN * A + i]; v->kind = B[MM_B_KIND * A + i];
+  }
+  e->steps = I[MM_E_STEPS * h->E + e_idx]; e->time = I[MM_E_TIME * h->E + e_idx];
+  e->n_merge = I[MM_E_N_MERGE * h->E + e_idx]; e->episode = I[MM_E_EPISODE * h->E + e_idx];
+}
+static void store_env(struct MMHandle_ *h, int64_t e_idx, const Env *e) {
+  const int64_t A = (int64_t)h->E * h->N, base = e_idx * h->N;
+  double *F = (double *)(h->state + h->lay.f64_offset);
+  uint8_t *B = h->state + h->lay.u8_offset;
+  int32_t *I = (int32_t *)(h->state + h->lay.env_offset);
+  for (int a = 0; a < h->N; a++) {
+    int64_t i = base + a;
+    if (a >= e->n) { B[MM_B_KIND * A + i] = 0; continue; }
+    const Veh *v = &e->v[a];
+    F[MM_F_X * A + i] = v->x; F[MM_F_Y * A + i] = v->y; F[MM_F_HEADING * A + i] = v->heading;
+    F[MM_F_SPEED * A + i] = v->speed; F[MM_F_TARGET_SPEED * A + i] = v->target_speed;
+    F[MM_F_SAFE_STEER * A + i] = v->safe_steer; F[MM_F_SAFE_ACC * A + i] = v->safe_acc;
+    F[MM_F_G_VX * A + i] = v->g_vx;
+    for (int k = 0; k < 4; k++) { F[(MM_F_H1_X + k) * A + i] = v->h1[k]; F[(MM_F_H2_X + k) * A + i] = v->h2[k]; }
+    B[MM_B_LANE * A + i] = (uint8_t)v->lane; B[MM_B_TARGET_LANE * A + i] = (uint8_t)v->target_lane;
+    B[MM_B_SPEED_INDEX * A + i] = (uint8_t)v->speed_index; B[MM_B_CRASHED * A + i] = (uint8_t)v->crashed;
+    B[MM_B_HL_ACTION * A + i] = (uint8_t)v->hl_action; B[MM_B_FLAGS * A + i] = (uint8_t)v->flags;
+    B[MM_B_HIST_LEN * A + i] = (uint8_t)v->hist_len; B[MM_B_KIND * A + i] = (uint8_t)v->kind;
+  }
+  I[MM_E_STEPS * h->E + e_idx] = e->steps; I[MM_E_TIME * h->E + e_idx] = e->time;
+  I[MM_E_N_MERGE * h->E + e_idx] = e->n_merge; I[MM_E_EPISODE * h->E + e_idx] = e->episode;
+}
+
+static void write_obs(const struct MMHandle_ *h, const Env *e, int64_t e_idx, void *obs, uint8_t *avail) {
+  const int F = h->cfg.env_kind == MM_ENV_V1 ? 6 : 5, S = 5 * F;
+  double row[30];
+  for (int a = 0; a < h->N; a++) {
+    if (a < e->n) observe_agent(&h->cfg, e, a, row);
+    else memset(row, 0, sizeof row);
+    int64_t o = (e_idx * h->N + a) * S;
+    if (obs) {
+      if (h->cfg.obs_f64) memcpy((double *)obs + o, row, S * sizeof(double));
+      else for (int k = 0; k < S; k++) ((float *)obs)[o + k] = (float)row[k];
+    }
+  }
+  if (avail) {
+    uint8_t m[MM_MAX_AGENTS * 5];
+    memset(m, 0, sizeof m);
+    action_mask(&h->cfg, e, m);
+    memcpy(avail + e_idx * h->N * 5, m, (size_t)h->N * 5);
+  }
+}
+
+/* ------------------------------------------------------------------ C ABI */
+
+int32_t mm_abi_version(void) { return MM_ABI_VERSION; }
+
+static uint64_t align256(uint64_t x) { return (x + 255u) & ~(uint64_t)255u; }
+
+int32_t mm_state_layout(int32_t E, int32_t N, MMStateLayout *out) {
+  if (!out || E <= 0 || N <= 0 || N > MM_MAX_AGENTS) return MM_ERR_INVALID_ARG;
+  uint64_t A = (uint64_t)E * (uint64_t)N, off = 0;
+  out->f64_offset = off; off = align256(off + A * 8u * MM_F_COUNT);
+  out->u8_offset = off; off = align256(off + A * MM_B_COUNT);
+  out->env_offset = off; off = align256(off + (uint64_t)E * 4u * MM_E_COUNT);
+  out->seed_offset = off; off = align256(off + (uint64_t)E * 8u);
+  out->total_bytes = off;
+  return MM_OK;
+}
+
+static int check_cfg(const MMConfig *c, int N, char *err) {
+  if (!c || c->abi_version != MM_ABI_VERSION) { snprintf(err, 256, "ABI version mismatch"); return MM_ERR_INVALID_ARG; }
+  if (c->env_kind != MM_ENV_V0 && c->env_kind != MM_ENV_V1) { snprintf(err, 256, "unknown env_kind %d", c->env_kind); return MM_ERR_INVALID_ARG; }
+  if (c->shield < MM_SHIELD_NONE || c->shield > MM_SHIELD_MASS) { snprintf(err, 256, "Undefined safety_type:%d", c->shield); return MM_ERR_INVALID_ARG; }
+  if (c->policy_frequency <= 0 || c->simulation_frequency < c->policy_frequency ||
+      c->simulation_frequency / c->policy_frequency > 3) { snprintf(err, 256, "unsupported frequencies"); return MM_ERR_INVALID_ARG; }
+  if (N > 12) { snprintf(err, 256, "N=%d exceeds the 6+6 spawn slots", N); return MM_ERR_INVALID_ARG; }
+  return MM_OK;
+}
+
+int32_t mm_create(const MMConfig *cfg, int32_t E, int32_t N, int32_t device, void *state,
+                  uint64_t state_bytes, int64_t first_env, MMHandle *out) {
+  (void)device;
+  if (!out || !state) return MM_ERR_INVALID_ARG;
+  struct MMHandle_ *h = calloc(1, sizeof *h);
+  if (mm_state_layout(E, N, &h->lay) != MM_OK || state_bytes < h->lay.total_bytes ||
+      check_cfg(cfg, N, h->err) != MM_OK) { free(h); return MM_ERR_INVALID_ARG; }
+  h->cfg = *cfg; h->E = E; h->N = N; h->state = state; h->first_env = first_env;
+  uint64_t *seeds = (uint64_t *)(h->state + h->lay.seed_offset);
+  for (int64_t e = 0; e < E; e++) seeds[e] = cfg->seed + (uint64_t)(first_env + e);
+  *out = h;
+  return MM_OK;
+}
+int32_t mm_destroy(MMHandle h) { free(h); return MM_OK; }
+int32_t mm_set_config(MMHandle h, const MMConfig *cfg) {
+  if (!h) return MM_ERR_INVALID_ARG;
+  int rc = check_cfg(cfg, h->N, h->err);
+  if (rc == MM_OK) h->cfg = *cfg;
+  return rc;
+}
+int32_t mm_set_metrics_buffer(MMHandle h, double *metrics) { h->metrics = metrics; return MM_OK; }
+const char *mm_last_error(MMHandle h) { return h ? h->err : "null handle"; }
+
+int32_t mm_reset(MMHandle h, const uint8_t *env_mask, const uint64_t *seeds_in, void *obs,
+                 uint8_t *avail, MMStream stream) {
+  (void)stream;
+  uint64_t *seeds = (uint64_t *)(h->state + h->lay.seed_offset);
+#pragma omp parallel for schedule(static)
+  for (int64_t e_idx = 0; e_idx < h->E; e_idx++) {
+    Env e;
+    if (env_mask && !env_mask[e_idx]) { load_env(h, e_idx, &e); write_obs(h, &e, e_idx, obs, avail); continue; }
+    load_env(h, e_idx, &e);
+    if (seeds_in) seeds[e_idx] = seeds_in[e_idx];
+    int episode = e.episode;
+    spawn_env(&e, h->N, seeds[e_idx], (uint32_t)episode);
+    e.episode = episode + 1;
+    store_env(h, e_idx, &e);
+    write_obs(h, &e, e_idx, obs, avail);
+  }
+  return MM_OK;
+}
+
+int32_t mm_init_from_kinematics(MMHandle h, const uint8_t *env_mask, MMStream stream) {
+  (void)stream;
+  const int64_t A = (int64_t)h->E * h->N;
+  const uint8_t *B = h->state + h->lay.u8_offset;
+#pragma omp parallel for schedule(static)
+  for (int64_t e_idx = 0; e_idx < h->E; e_idx++) {
+    if (env_mask && !env_mask[e_idx]) continue;
+    Env e;
+    load_env(h, e_idx, &e);
+    int n_m = 0;
+    for (int a = 0; a < e.n; a++) {
+      init_vehicle(&e.v[a]);
+      if (e.v[a].lane == MM_LANE_JK0) n_m++;
+    }
+    (void)A; (void)B;
+    e.steps = e.time = 0; e.n_merge = n_m;
+    store_env(h, e_idx, &e);
+  }
+  return MM_OK;
+}
+
+int32_t mm_observe(MMHandle h, void *obs, uint8_t *avail, MMStream stream) {
+  (void)stream;
+#pragma omp parallel for schedule(static)
+  for (int64_t e_idx = 0; e_idx < h->E; e_idx++) {
+    Env e;
+    load_env(h, e_idx, &e);
+    write_obs(h, &e, e_idx, obs, avail);
+  }
+  return MM_OK;
+}
+
+int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStream stream) {
+  (void)stream;
+  if (!h || !actions || !out) return MM_ERR_INVALID_ARG;
+  const MMConfig *cfg = &h->cfg;
+  const int64_t A = (int64_t)h->E * h->N;
+  int rc_all = MM_OK;
+  uint64_t *seeds = (uint64_t *)(h->state + h->lay.seed_offset);
+  if (out->trace)
+    for (int64_t k = 0; k < 3 * (int64_t)MM_T_COUNT * A; k++) out->trace[k] = NAN;
+  double m_sum[7] = {0}, m_min = INFINITY;
+#pragma omp parallel for schedule(static) reduction(+ : m_sum[:7]) reduction(min : m_min)
+  for (int64_t e_idx = 0; e_idx < h->E; e_idx++) {
+    Env e;
+    load_env(h, e_idx, &e);
+    const int64_t base = e_idx * h->N;
+    if (e.n == 0) continue;
+    e.steps += 1; /* abstract.py:457 */
+    int rc = simulate(cfg, &e, actions + base, out->trace, A, base);
+    if (rc) {
+#pragma omp critical
+      { rc_all = rc; snprintf(h->err, sizeof h->err, "Error in QP. Invalid accceleration (env %lld)", (long long)e_idx); }
+    }
+    /* AbstractEnv.step abstract.py:469-498 then MergeEnv.step merge_env_v1.py:126-166 */
+    int done = is_terminal(cfg, &e);
+    double rsum = 0, ssum = 0;
+    for (int i = 0; i < e.n; i++) {
+      e.v[i].local_reward = agent_reward(cfg, &e, i);
+      rsum += e.v[i].local_reward;
+      ssum += e.v[i].speed;
+    }
+    double reward = rsum / e.n, avg_speed = ssum / e.n;
+    regional_reward(&e);
+    double mh = min_time_headway(&e);
+    double merge_pct = NAN;
+    int any_crashed = 0;
+    for (int i = 0; i < e.n; i++) any_crashed |= e.v[i].crashed;
+    if (done) {
+      int n_rem = 0;
+      for (int i = 0; i < e.n; i++)
+        if (e.v[i].lane == MM_LANE_BC1 || e.v[i].lane == MM_LANE_KB0 || e.v[i].lane == MM_LANE_JK0) n_rem++;
+      merge_pct = e.n_merge > 0 ? (double)(e.n_merge - n_rem) / e.n_merge * 100 : 100.0;
+    }
+    if (out->reward) out->reward[e_idx] = reward;
+    if (out->done) out->done[e_idx] = (uint8_t)done;
+    if (out->average_speed) out->average_speed[e_idx] = avg_speed;
+    if (out->traffic_speed) out->traffic_speed[e_idx] = avg_speed; /* CAV-only: road.vehicles == controlled */
+    if (out->min_headway) out->min_headway[e_idx] = mh;
+    if (out->merge_percent) out->merge_percent[e_idx] = merge_pct;
+    const int T = cfg->duration * cfg->policy_frequency;
+    for (int a = 0; a < h->N; a++) {
+      const int live = a < e.n;
+      const Veh *v = &e.v[a];
+      if (out->agents_rewards) out->agents_rewards[base + a] = live ? v->local_reward : 0;
+      if (out->regional_rewards) out->regional_rewards[base + a] = live ? v->regional_reward : 0;
+      if (out->agents_dones) /* merge_env_v1.py:174-178 */
+        out->agents_dones[base + a] = live ? (uint8_t)(v->crashed || e.steps >= T || v->x < 0) : 1;
+      if (out->crashed) out->crashed[base + a] = live ? (uint8_t)v->crashed : 0;
+      if (out->agents_info) {
+        out->agents_info[(base + a) * 3 + 0] = live ? v->x : 0;
+        out->agents_info[(base + a) * 3 + 1] = live ? v->y : 0;
+        out->agents_info[(base + a) * 3 + 2] = live ? v->speed : 0;
+      }
+    }
+    m_sum[0] += reward; m_sum[2] += avg_speed; m_sum[3] += avg_speed; m_sum[4] += 1;
+    if (done) { m_sum[1] += any_crashed; m_sum[5] += merge_pct; m_sum[6] += 1; }
+    if (mh < m_min) m_min = mh;
+    if (done && cfg->auto_reset) { /* caller-side `if done: env.reset()` (marl/mappo.py:133-135) */
+      int episode = e.episode;
+      spawn_env(&e, h->N, seeds[e_idx], (uint32_t)episode);
+      e.episode = episode + 1;
+    }
+    store_env(h, e_idx, &e);
+    write_obs(h, &e, e_idx, out->obs, out->action_mask);
+  }
+  if (h->metrics) {
+    for (int k = 0; k < 7; k++) h->metrics[k] += m_sum[k];
+    if (m_min < h->metrics[7]) h->metrics[7] = m_min;
+  }
+  return rc_all;
+}
+
+int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec,
+                     const int32_t *rows, double *u_out, uint8_t *status, MMStream stream) {
+  (void)h; (void)stream;
+  for (int k = 0; k < n; k++) {
+    const double *g = G + (int64_t)k * 12, *hh = hvec + (int64_t)k * 4;
+    double a = g[0], hc = hh[0];
+    if (rows[k] == 4 && hh[3] < hc) hc = hh[3];
+    double hi = hh[1], lo = -hh[2], d;
+    if (a > 0) d = fmin(0.0, hc / a);
+    else if (a < 0) d = fmax(0.0, hc / a);
+    else d = 0.0;
+    d = fmin(fmax(d, lo), hi);
+    double s = a * d - hc;
+    u_out[k * 3 + 0] = d; u_out[k * 3 + 1] = 0.0; u_out[k * 3 + 2] = s > 0 ? s : 0.0;
+    if (status) status[k] = 1;
+  }
+  return MM_OK;
+}
+
+/* ------------------------------------------------------------------ unit hooks for tests */
+/* Pure functions exposed so tests can pin them against tests/golden/units.npz. */
+int32_t orc_closest_lane(double x, double y, double h) { return closest_lane(x, y, h); }
+int32_t orc_next_lane(int32_t lane, double x, double y) { return next_lane(lane, x, y); }
+void orc_lane_local(int32_t lane, double x, double y, double *s, double *r) { lane_local(lane, x, y, s, r); }
+double orc_lane_heading_at(int32_t lane, double s) { return lane_heading_at(lane, s); }
+double orc_lane_distance_with_heading(int32_t lane, double x, double y, double h) { return lane_distance_with_heading(lane, x, y, h); }
+int32_t orc_on_lane(int32_t lane, double x, double y) { return lane_on_lane(lane, x, y); }
+int32_t orc_is_reachable_from(int32_t lane, double x, double y) { return lane_is_reachable_from(lane, x, y); }
+int32_t orc_after_end(int32_t lane, double x, double y) { return lane_after_end(lane, x, y); }
+double orc_steering_control(double x, double y, double heading, double speed, int32_t target_lane) {
+  Veh v; memset(&v, 0, sizeof v); v.x = x; v.y = y; v.heading = heading; v.speed = speed;
+  return steering_control(&v, target_lane);
+}
+void orc_get_corner(double x, double y, double heading, int32_t dir, double *cx, double *cy) {
+  Veh v; memset(&v, 0, sizeof v); v.x = x; v.y = y; v.heading = heading;
+  get_corner(&v, dir, cx, cy);
+}
+int32_t orc_speed_to_index(double speed) { return speed_to_index(speed); }
+double orc_wrap_to_pi(double x) { return wrap_to_pi(x); }
+int32_t orc_rect_intersect(double c1x, double c1y, double l1, double w1, double a1, double c2x,
+                           double c2y, double l2, double w2, double a2) {
+  return rotated_rectangles_intersect(c1x, c1y, l1, w1, a1, c2x, c2y, l2, w2, a2);
+}
+
+/* batched forms of the unit hooks (keeps the CPU test-suite fast) */
+void orc_batch_pose(int32_t n, const double *x, const double *y, const double *h, double *local /*[n][6][2]*/,
+                    double *lane_heading /*[n][6]*/, double *dist /*[n][6]*/, uint8_t *onlane, uint8_t *reach,
+                    uint8_t *after, int32_t *nxt /*[n][6]*/, int32_t *closest /*[n]*/) {
+  for (int k = 0; k < n; k++) {
+    for (int l = 0; l < 6; l++) {
+      double s, r;
+      lane_local(l, x[k], y[k], &s, &r);
+      local[(k * 6 + l) * 2] = s; local[(k * 6 + l) * 2 + 1] = r;
+      lane_heading[k * 6 + l] = lane_heading_at(l, s);
+      dist[k * 6 + l] = lane_distance_with_heading(l, x[k], y[k], h[k]);
+      onlane[k * 6 + l] = (uint8_t)lane_on_lane(l, x[k], y[k]);
+      reach[k * 6 + l] = (uint8_t)lane_is_reachable_from(l, x[k], y[k]);
+      after[k * 6 + l] = (uint8_t)lane_after_end(l, x[k], y[k]);
+      nxt[k * 6 + l] = next_lane(l, x[k], y[k]);
+    }
+    closest[k] = closest_lane(x[k], y[k], h[k]);
+  }
+}
+void orc_batch_steering(int32_t n, const double *x, const double *y, const double *h, const double *v,
+                        const int32_t *lane, double *steer, double *corner /*[n][2][2]*/) {
+  for (int k = 0; k < n; k++) {
+    steer[k] = orc_steering_control(x[k], y[k], h[k], v[k], lane[k]);
+    orc_get_corner(x[k], y[k], h[k], 0, &corner[k * 4 + 0], &corner[k * 4 + 1]);
+    orc_get_corner(x[k], y[k], h[k], 1, &corner[k * 4 + 2], &corner[k * 4 + 3]);
+  }
+}
+void orc_batch_rect(int32_t n, const double *rect /*[n][6]*/, uint8_t *hit, uint8_t *hit_obstacle) {
+  for (int k = 0; k < n; k++) {
+    const double *r = rect + k * 6;
+    hit[k] = (uint8_t)rotated_rectangles_intersect(r[0], r[1], 4.5, 1.8, r[2], r[3], r[4], 4.5, 1.8, r[5]);
+    hit_obstacle[k] = (uint8_t)rotated_rectangles_intersect(r[0], r[1], 4.5, 1.8, r[2], r[3], r[4], 1.8, 1.8, 0.0);
+  }
+}

@@ -1,0 +1,83 @@
+"""Pins the CPU oracle (oracle/mm_oracle.c) against vectors produced by the reference itself."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_env
+from golden_util import GOLDEN, episode_files, replay
+
+
+@pytest.fixture(scope="module")
+def units():
+    return np.load(os.path.join(GOLDEN, "units.npz"))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return oracle_env.library().lib
+
+
+def test_lane_constants(units):
+    """merge_env_v1.py:222-248: the lane table the restatement hard-codes."""
+    np.testing.assert_array_equal(units["lane_start"], [[0, 0], [320, 0], [320, 4], [420, 0], [0, 10.5], [220, 7.25]])
+    np.testing.assert_array_equal(units["lane_length"], [320, 100, 100, 1000, 220, 100])
+    np.testing.assert_array_equal(units["lane_forbidden"], [0, 0, 1, 0, 1, 1])
+    np.testing.assert_array_equal(units["sine"], [3.25, 2 * np.pi / 200, np.pi / 2])
+    np.testing.assert_array_equal(units["obstacle"], [420, 4])
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_lane_frames_and_argmin(units, lib):
+    x, y, h = (np.ascontiguousarray(units[k]) for k in ("pose_x", "pose_y", "pose_h"))
+    n = len(x)
+    local, lh, dist = np.zeros((n, 6, 2)), np.zeros((n, 6)), np.zeros((n, 6))
+    on, reach, after = (np.zeros((n, 6), dtype=np.uint8) for _ in range(3))
+    nxt, closest = np.zeros((n, 6), dtype=np.int32), np.zeros(n, dtype=np.int32)
+    lib.orc_batch_pose(n, _p(x), _p(y), _p(h), _p(local), _p(lh), _p(dist), _p(on), _p(reach), _p(after),
+                       _p(nxt), _p(closest))
+    np.testing.assert_allclose(local, units["local"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(lh, units["lane_heading"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(dist, units["dist_heading"], rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(on, units["on_lane"])
+    np.testing.assert_array_equal(reach, units["reachable"])
+    np.testing.assert_array_equal(after, units["after_end"])
+    np.testing.assert_array_equal(nxt, units["next_lane"])
+    np.testing.assert_array_equal(closest, units["closest"])
+
+
+def test_steering_control_and_corners(units, lib):
+    x, y, h, v = (np.ascontiguousarray(units[k]) for k in ("sc_x", "sc_y", "sc_h", "sc_v"))
+    lane = np.ascontiguousarray(units["sc_lane"], dtype=np.int32)
+    n = len(x)
+    steer, corner = np.zeros(n), np.zeros((n, 2, 2))
+    lib.orc_batch_steering(n, _p(x), _p(y), _p(h), _p(v), _p(lane), _p(steer), _p(corner))
+    np.testing.assert_allclose(steer, units["sc_steer"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(corner, units["corner"], rtol=0, atol=1e-12)
+
+
+def test_scalar_helpers(units, lib):
+    for s, i in zip(units["sti_speed"], units["sti_index"]):
+        assert lib.orc_speed_to_index(float(s)) == i
+    for a, w in zip(units["wrap_in"], units["wrap_out"]):
+        assert lib.orc_wrap_to_pi(float(a)) == w  # fmod-based: exact
+
+
+def test_rotated_rectangles(units, lib):
+    r = np.ascontiguousarray(units["rect"])
+    hit, hit_o = np.zeros(len(r), dtype=np.uint8), np.zeros(len(r), dtype=np.uint8)
+    lib.orc_batch_rect(len(r), _p(r), _p(hit), _p(hit_o))
+    np.testing.assert_array_equal(hit, units["rect_hit"])
+    np.testing.assert_array_equal(hit_o, units["rect_hit_obstacle"])
+
+
+@pytest.mark.parametrize("path", episode_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_episode_tape(path):
+    """Full env.step parity: per-sub-step state, QP rows, obs, rewards, dones, info."""
+    err = replay(oracle_env.OracleEnv, path)
+    print(os.path.basename(path), json.dumps({k: float("%.3g" % v) for k, v in err.items()}))
