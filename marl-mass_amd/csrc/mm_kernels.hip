@@ -1,0 +1,1087 @@
+// mm_kernels.hip -- fused env.step / reset / observe kernels + the C ABI of include/mm_abi.h.
+//
+// Mapping (CDNA4, wave64): one LANE per vehicle, the G = pow2 >= N lanes of an env are contiguous
+// in a wave ("env group"), 64/G envs per wave, 256-thread blocks.  All cross-vehicle reads of an
+// env (neighbour search, collision, observation, rewards, shield) are wave shuffles inside the
+// group: no LDS tiles, no __syncthreads, no inter-workgroup traffic.  One launch = one env.step
+// for every env: 3 simulation sub-steps + rewards/info + optional re-spawn + observation.
+//
+// Sub-step structure (reference: abstract.py:512-532, road.py:269-292):
+//   act      per-lane  ControlledVehicle.act: follow_road, steering/speed control
+//   predict  per-lane  bicycle integration + lane argmin + corner tests for the nominal steering
+//                      (and for the LC-veto steering when it can differ) -- ALL transcendentals
+//                      live here, at full lane utilisation
+//   sweep    serial    front-to-back Gauss-Seidel over the env's vehicles (road.py:286): the CBF
+//                      state assembly + closed-form QP + LC veto of one vehicle per stage; only
+//                      selects between the predicted post-states, so a stage is ~40 shuffles and
+//                      ~150 fp64 ops.  Followers see leaders' committed post-step state.
+//   collide  per-lane  pair tests by xor-shuffle; the rare order-dependent speed fix-up is serial
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "mm_device.h"
+
+using namespace mm;
+
+struct DevCfg {
+  int env_kind, shield, nsub, T, action_masking, auto_reset, obs_f64, N;
+  double dt, collision_reward, high_speed_reward, headway_cost, headway_time, merging_lane_cost;
+  double rs_lo, rs_hi, eta, tau;
+};
+struct DevState {
+  double *F;
+  uint8_t *B;
+  int32_t *I;
+  uint64_t *seeds;
+  long long A;
+  int E, N;
+};
+
+struct Veh {
+  double x, y, h, v, tspeed;
+  double act_steer, act_acc, safe_steer, safe_acc, gvx;
+  double h1x, h1h, h1vx, h1v, h2x, h2h, h2vx, h2v;
+  int lane, tlane, sidx, crashed, hl, flags, hist_len;
+  bool present;
+};
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers (64 lanes; an env group never straddles a wave)
+// ------------------------------------------------------------------------------------------------
+MM_DEV int lane_id() { return threadIdx.x & 63; }
+MM_DEV double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+MM_DEV int shfl_i(int v, int src) { return __shfl(v, src, 64); }
+MM_DEV double shflx_d(double v, int m) { return __shfl_xor(v, m, 64); }
+MM_DEV int shflx_i(int v, int m) { return __shfl_xor(v, m, 64); }
+template <int G>
+MM_DEV unsigned group_ballot(bool p, int gb) {
+  unsigned long long b = __ballot(p);
+  return (unsigned)((b >> gb) & ((1ull << G) - 1ull));
+}
+MM_DEV void atomic_min_d(double *addr, double val) {  // CAS loop: valid for any sign, LDS or global
+  unsigned long long *p = (unsigned long long *)addr, old = *p, assumed;
+  do {
+    assumed = old;
+    if (__longlong_as_double((long long)assumed) <= val) break;
+    old = atomicCAS(p, assumed, (unsigned long long)__double_as_longlong(val));
+  } while (assumed != old);
+}
+template <int G>
+MM_DEV double group_min_d(double v) {
+#pragma unroll
+  for (int m = 1; m < G; m <<= 1) v = fmin(v, shflx_d(v, m));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// state load / store
+// ------------------------------------------------------------------------------------------------
+MM_DEV void load_veh(const DevState &st, long long i, bool valid, Veh &v) {
+  memset(&v, 0, sizeof v);
+  v.present = false;
+  v.hl = MM_HL_NONE;
+  if (!valid) return;
+  const long long A = st.A;
+  v.present = st.B[MM_B_KIND * A + i] != 0;
+  if (!v.present) return;
+  v.x = st.F[MM_F_X * A + i]; v.y = st.F[MM_F_Y * A + i]; v.h = st.F[MM_F_HEADING * A + i];
+  v.v = st.F[MM_F_SPEED * A + i]; v.tspeed = st.F[MM_F_TARGET_SPEED * A + i];
+  v.safe_steer = st.F[MM_F_SAFE_STEER * A + i]; v.safe_acc = st.F[MM_F_SAFE_ACC * A + i];
+  v.gvx = st.F[MM_F_G_VX * A + i];
+  v.h1x = st.F[MM_F_H1_X * A + i]; v.h1h = st.F[MM_F_H1_HEADING * A + i];
+  v.h1vx = st.F[MM_F_H1_VX * A + i]; v.h1v = st.F[MM_F_H1_SPEED * A + i];
+  v.h2x = st.F[MM_F_H2_X * A + i]; v.h2h = st.F[MM_F_H2_HEADING * A + i];
+  v.h2vx = st.F[MM_F_H2_VX * A + i]; v.h2v = st.F[MM_F_H2_SPEED * A + i];
+  v.lane = st.B[MM_B_LANE * A + i]; v.tlane = st.B[MM_B_TARGET_LANE * A + i];
+  v.sidx = st.B[MM_B_SPEED_INDEX * A + i]; v.crashed = st.B[MM_B_CRASHED * A + i];
+  v.hl = st.B[MM_B_HL_ACTION * A + i]; v.flags = st.B[MM_B_FLAGS * A + i];
+  v.hist_len = st.B[MM_B_HIST_LEN * A + i];
+}
+MM_DEV void store_veh(const DevState &st, long long i, const Veh &v) {
+  const long long A = st.A;
+  st.F[MM_F_X * A + i] = v.x; st.F[MM_F_Y * A + i] = v.y; st.F[MM_F_HEADING * A + i] = v.h;
+  st.F[MM_F_SPEED * A + i] = v.v; st.F[MM_F_TARGET_SPEED * A + i] = v.tspeed;
+  st.F[MM_F_SAFE_STEER * A + i] = v.safe_steer; st.F[MM_F_SAFE_ACC * A + i] = v.safe_acc;
+  st.F[MM_F_G_VX * A + i] = v.gvx;
+  st.F[MM_F_H1_X * A + i] = v.h1x; st.F[MM_F_H1_HEADING * A + i] = v.h1h;
+  st.F[MM_F_H1_VX * A + i] = v.h1vx; st.F[MM_F_H1_SPEED * A + i] = v.h1v;
+  st.F[MM_F_H2_X * A + i] = v.h2x; st.F[MM_F_H2_HEADING * A + i] = v.h2h;
+  st.F[MM_F_H2_VX * A + i] = v.h2vx; st.F[MM_F_H2_SPEED * A + i] = v.h2v;
+  st.B[MM_B_LANE * A + i] = (uint8_t)v.lane; st.B[MM_B_TARGET_LANE * A + i] = (uint8_t)v.tlane;
+  st.B[MM_B_SPEED_INDEX * A + i] = (uint8_t)v.sidx; st.B[MM_B_CRASHED * A + i] = (uint8_t)v.crashed;
+  st.B[MM_B_HL_ACTION * A + i] = (uint8_t)v.hl; st.B[MM_B_FLAGS * A + i] = (uint8_t)v.flags;
+  st.B[MM_B_HIST_LEN * A + i] = (uint8_t)v.hist_len;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-vehicle control (controller.py)
+// ------------------------------------------------------------------------------------------------
+// controller.py:90-134 ControlledVehicle.act; action 0 LEFT / 2 RIGHT change lanes, else none
+MM_DEV void controlled_act(Veh &v, int action) {
+  if (lane_after_end(v.tlane, v.x)) v.tlane = next_lane(v.tlane, v.x, v.y);  // follow_road :136-144
+  if (action == 2 || action == 0) {
+    // only road (b,c) has two lanes; elsewhere the clipped candidate is the lane itself
+    int cand = v.tlane;
+    if (lane_road(v.tlane) == 1) cand = (action == 2) ? MM_LANE_BC1 : MM_LANE_BC0;
+    if (lane_reachable(cand, v.x, v.y)) v.tlane = cand;
+  }
+  double steer = steering_control(v.x, v.y, v.h, v.v, v.tlane);
+  v.act_acc = (1 / kTauA) * (v.tspeed - v.v);  // speed_control :189-197
+  v.act_steer = clipd(steer, -kPi / 3, kPi / 3);
+}
+// controller.py:293-311 MDPVehicle.act (+ safe_controller.py:63-66 hl_action)
+template <int KIND>
+MM_DEV void mdp_act(Veh &v, int action) {
+  if (KIND == MM_ENV_V1 && action >= 0) v.hl = action;
+  if (action == 3 || action == 4) {
+    int si = speed_to_index(v.v) + (action == 3 ? 1 : -1);
+    v.sidx = si < 0 ? 0 : (si > 4 ? 4 : si);
+    v.tspeed = index_to_speed(v.sidx);
+    controlled_act(v, -1);
+  } else {
+    controlled_act(v, action);
+  }
+}
+
+// kinematics.py:143-152 clip_actions (+ safe_controller.py:100-104)
+template <int KIND>
+MM_DEV void clip_actions(Veh &v) {
+  if (v.crashed) { v.act_steer = 0; v.act_acc = -1.0 * v.v; }
+  if (v.v > kMaxSpeed) v.act_acc = fmin(v.act_acc, 1.0 * (kMaxSpeed - v.v));
+  else if (v.v < -kMaxSpeed) v.act_acc = fmax(v.act_acc, 1.0 * (kMaxSpeed - v.v));
+  if (KIND == MM_ENV_V1) v.act_acc = clipd(v.act_acc, kLcMinAcc, kLcMaxAcc);
+}
+
+// controller.py:257-267 get_corner("L"/"R") + lane.on_lane of those corners on `lane`
+MM_DEV void corner_flags(double x, double y, double h, int lane, bool &offL, bool &offR) {
+  double cx = x + (kCornerLen * cos(kCornerAlpha + h));
+  double cyL = y - (kCornerLen * sin(kCornerAlpha + h)) + 0.01;
+  double cyR = y - (kCornerLen * sin(-kCornerAlpha + h)) + 0.01;
+  double s = cx - lane_sx(lane);
+  double off = (lane == MM_LANE_KB0) ? kSineAmp * sin(kSinePuls * s + kSinePhase) : 0.0;
+  bool lon = (-kVehLength <= s && s < lane_len(lane) + kVehLength);
+  double rL = cyL - lane_sy(lane), rR = cyR - lane_sy(lane);
+  if (lane == MM_LANE_KB0) { rL = rL - off; rR = rR - off; }
+  offL = !(fabs(rL) <= kLaneWidth / 2 + 0 && lon);
+  offR = !(fabs(rR) <= kLaneWidth / 2 + 0 && lon);
+}
+
+// Predicted post-state of Vehicle.step for a given steering (kinematics.py:122-141,
+// safe_controller.py:151-172): everything that does not depend on the acceleration.
+struct Cand {
+  double x, y, h, gvx, cpsi;
+  int lane;
+  bool offL, offR;
+};
+template <int KIND, bool SHIELDED>
+MM_DEV Cand predict(const Veh &v, double steer, double dt) {
+  Cand c;
+  double beta = atan(1.0 / 2 * tan(steer));
+  double vx = v.v * cos(v.h + beta), vy = v.v * sin(v.h + beta);
+  c.x = v.x + vx * dt;
+  c.y = v.y + vy * dt;
+  c.h = v.h + v.v * sin(beta) / (kVehLength / 2) * dt;
+  c.gvx = (KIND == MM_ENV_V1) ? cos(c.h + beta) : 0.0;
+  c.lane = closest_lane(c.x, c.y, c.h);  // on_state_update kinematics.py:154-159
+  c.cpsi = (KIND == MM_ENV_V1) ? cos(c.h) : 0.0;
+  c.offL = c.offR = false;
+  if (SHIELDED) corner_flags(c.x, c.y, c.h, c.lane, c.offL, c.offR);
+  return c;
+}
+
+// decentral_layer.py:23-39 is_adj_lane(vehicle, lane2) given vehicle.lane and its next_lane
+MM_DEV int adj_lane(int l1, int nl1, int l2) {
+  if (lane_road(l1) == lane_road(l2) && abs(lane_rid(l1) - lane_rid(l2)) == 1) return lane_rid(l1) - lane_rid(l2);
+  if (lane_road(nl1) == lane_road(l2) && abs(lane_rid(nl1) - lane_rid(l2)) == 1) return lane_rid(nl1) - lane_rid(l2);
+  return 0;
+}
+
+struct QpTrace {
+  double rows, a, h0, h1, h2, h3, d;
+};
+
+// ------------------------------------------------------------------------------------------------
+// device reset: merge_env_v1.py:265-364 with the Philox stream documented in DESIGN.md
+// ------------------------------------------------------------------------------------------------
+MM_DEV void init_vehicle(Veh &v) {  // kinematics.py:36-53, controller.py:35-50,277-291, safe_controller.py:27-61
+  v.lane = closest_lane(v.x, v.y, v.h);
+  v.tlane = v.lane;
+  v.sidx = speed_to_index(v.v);
+  v.tspeed = index_to_speed(v.sidx);
+  v.act_steer = v.act_acc = 0;
+  v.safe_steer = v.safe_acc = 0;
+  v.gvx = __builtin_nan("");
+  v.h1x = v.h1h = v.h1vx = v.h1v = 0;
+  v.h2x = v.h2h = v.h2vx = v.h2v = 0;
+  v.crashed = 0; v.hl = MM_HL_NONE; v.flags = 0; v.hist_len = 0;
+}
+MM_DEV int spawn_vehicle(Veh &v, int a, int N, uint64_t seed, uint32_t episode) {
+  uint32_t r[12], blk[4];
+  rng_block(seed, episode, 0, &r[0]);
+  rng_block(seed, episode, 1, &r[4]);
+  rng_block(seed, episode, 2, &r[8]);
+  int n_s = (N != 1) ? N / 2 : (int)(r[0] & 1u);
+  int n_m = N - n_s;
+  bool main_road = a < n_s;
+  int k = main_road ? a : a - n_s;
+  int slots[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) slots[i] = (main_road ? 10 : 5) + 50 * i;
+  int chosen = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {  // partial Fisher-Yates == choice(replace=False)
+    if (i <= k) {
+      const uint32_t ri = main_road ? r[i] : r[6 + i];
+      int j = i + (int)(((uint64_t)ri * (uint32_t)(6 - i)) >> 32);
+      int si = slots[i], sj = 0;
+#pragma unroll
+      for (int q = 0; q < 6; q++) if (q == j) sj = slots[q];
+#pragma unroll
+      for (int q = 0; q < 6; q++) if (q == j) slots[q] = si;
+      slots[i] = sj;
+      if (i == k) chosen = sj;
+    }
+  }
+  rng_block(seed, episode, 3u + (uint32_t)a, blk);
+  double speed = u53(blk[0], blk[1]) * 2 + 25;
+  double noise = u53(blk[2], blk[3]) * 8 - 4;
+  v.x = chosen + noise;
+  v.y = main_road ? 0.0 : 10.5;
+  v.h = 0;
+  v.v = speed;
+  v.present = true;
+  init_vehicle(v);
+  return n_m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// observation (envs/common/observation.py:181-273) + action mask (abstract.py:219-240)
+// ------------------------------------------------------------------------------------------------
+template <int G, int KIND, typename OBS_T>
+MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, bool valid, OBS_T *obs,
+                    uint8_t *avail) {
+  constexpr int F = (KIND == MM_ENV_V1) ? 6 : 5;
+  const double cps = cos(v.h), sps = sin(v.h);
+  const double vx = v.v * cps, vy = v.v * sps;  // Vehicle.velocity kinematics.py:215-217
+  const double sx = lane_sx(v.lane);
+  double key[G];
+  key[0] = 0;
+#pragma unroll
+  for (int m = 1; m < G; m++) {
+    double px = shflx_d(v.x, m), py = shflx_d(v.y, m);
+    bool pp = shflx_i((int)v.present, m) != 0;
+    double dx = px - v.x, dy = py - v.y;
+    bool close = pp && sqrt(dx * dx + dy * dy) < kPerception;  // road.py:259-262
+    key[m] = close ? fabs((px - sx) - (v.x - sx)) : INFINITY;   // |lane_distance_to| kinematics.py:161-173
+  }
+  double row[4][F - 1];
+  bool have[4] = {false, false, false, false};
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int f = 0; f < F - 1; f++) row[q][f] = 0;
+#pragma unroll
+  for (int m = 1; m < G; m++) {
+    int rank = 0;  // position in sorted(key=|lane distance|) (stable: ties keep creation order)
+#pragma unroll
+    for (int m2 = 1; m2 < G; m2++)
+      if (m2 != m) rank += (key[m2] < key[m] || (key[m2] == key[m] && (a ^ m2) < (a ^ m))) ? 1 : 0;
+    double px = shflx_d(v.x, m), py = shflx_d(v.y, m), pvx = shflx_d(vx, m), pvy = shflx_d(vy, m);
+    double ph = (KIND == MM_ENV_V1) ? shflx_d(v.h, m) : 0.0;
+    bool use = key[m] < INFINITY;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (use && rank == q) {
+        have[q] = true;
+        row[q][0] = px - v.x; row[q][1] = py - v.y; row[q][2] = pvx - vx; row[q][3] = pvy - vy;
+        if (KIND == MM_ENV_V1) row[q][F - 2] = ph;
+      }
+    }
+  }
+  if (valid && obs) {
+    // normalize_obs :181-193 via utils.lmap :16-18 (no clip); ranges :171-176, :238-239
+    const double lo[5] = {-5.0 * 30, -12, -1.5 * 30, -1.5 * 30, -kPi / 2};
+    const double hi[5] = {5.0 * 30, 12, 1.5 * 30, 1.5 * 30, kPi / 2};
+    OBS_T *o = obs + i * (5 * F);
+    if (!v.present) {
+#pragma unroll
+      for (int k = 0; k < 5 * F; k++) o[k] = (OBS_T)0;
+    } else {
+      const double ego[5] = {v.x, v.y, vx, vy, v.h};
+      o[0] = (OBS_T)1;
+#pragma unroll
+      for (int f = 0; f < F - 1; f++) o[1 + f] = (OBS_T)(-1 + (ego[f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f]));
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        o[(q + 1) * F] = have[q] ? (OBS_T)1 : (OBS_T)0;
+#pragma unroll
+        for (int f = 0; f < F - 1; f++)
+          o[(q + 1) * F + 1 + f] =
+              have[q] ? (OBS_T)(-1 + (row[q][f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f])) : (OBS_T)0;
+      }
+    }
+  }
+  // action mask: with masking on, the reference's `[[0]*n_a]*n` aliases every row (abstract.py:202,475)
+  // so each agent gets the OR over all agents; with masking off every action is available.
+  unsigned bits = 0x1F;
+  if (c.action_masking) {
+    unsigned mine = 0;
+    if (v.present) {
+      mine = 1u << 1;
+      if (v.lane == MM_LANE_BC1 && lane_reachable(MM_LANE_BC0, v.x, v.y)) mine |= 1u << 0;
+      if (v.lane == MM_LANE_BC0 && lane_reachable(MM_LANE_BC1, v.x, v.y)) mine |= 1u << 2;
+      if (v.sidx < 4) mine |= 1u << 3;
+      if (v.sidx > 0) mine |= 1u << 4;
+    }
+    bits = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+      if (group_ballot<G>((mine >> k) & 1u, gb)) bits |= 1u << k;
+  }
+  if (valid && avail) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) avail[i * 5 + k] = v.present ? (uint8_t)((bits >> k) & 1u) : (uint8_t)0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused step kernel
+// ------------------------------------------------------------------------------------------------
+template <int G, int KIND, int SHIELD, typename OBS_T>
+__global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
+                                                   MMStepOut out, double *metrics) {
+  constexpr bool LC = (KIND == MM_ENV_V1);
+  constexpr bool SHIELDED = LC && (SHIELD != MM_SHIELD_NONE);
+  constexpr bool MASS = (SHIELD == MM_SHIELD_MASS);
+  const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e = gtid / G;
+  const int a = (int)(gtid % G);
+  const int gb = lane_id() & ~(G - 1);
+  const bool valid = e < st.E && a < st.N;
+  const long long i = e * st.N + a;
+  const long long A = st.A;
+  const double dt = c.dt;
+
+  Veh v;
+  load_veh(st, i, valid, v);
+  int steps = 0, time = 0, n_merge = 0, episode = 0;
+  if (e < st.E) {
+    steps = st.I[MM_E_STEPS * st.E + e]; time = st.I[MM_E_TIME * st.E + e];
+    n_merge = st.I[MM_E_N_MERGE * st.E + e]; episode = st.I[MM_E_EPISODE * st.E + e];
+  }
+  const int action = (valid && v.present) ? actions[i] : 1;
+  const unsigned present_bits = group_ballot<G>(v.present, gb);
+  const int n_veh = __popc(present_bits);
+  steps += 1;  // abstract.py:457
+
+  // derived per-vehicle registers the shield keeps current across sub-steps
+  double cpsi = (SHIELDED && v.present) ? cos(v.h) : 1.0;
+  bool offL = false, offR = false;
+  int nl_self = 0;
+  if (SHIELDED && v.present) {
+    corner_flags(v.x, v.y, v.h, v.lane, offL, offR);
+    nl_self = next_lane(v.lane, v.x, v.y);
+  }
+
+  bool env_active = n_veh > 0;
+  for (int k = 0; k < c.nsub; k++) {
+    const bool live = env_active && v.present;
+    QpTrace qt = {0, __builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan(""),
+                  __builtin_nan(""), __builtin_nan("")};
+    if (live) {
+      if (time % c.nsub == 0) mdp_act<KIND>(v, action);  // action_type.act abstract.py:516-519
+      mdp_act<KIND>(v, -1);                              // road.act road.py:269-278
+      clip_actions<KIND>(v);
+    }
+    // Road.step order: sorted by x descending, stable (road.py:286)
+    int rank = 0;
+#pragma unroll
+    for (int m = 1; m < G; m++) {
+      double px = shflx_d(v.x, m);
+      bool pp = shflx_i((int)v.present, m) != 0;
+      rank += (pp && (px > v.x || (px == v.x && (a ^ m) < a))) ? 1 : 0;
+    }
+    // predicted post-state for the nominal steering (the only one when nothing vetoes)
+    Cand cA, cB;
+    memset(&cA, 0, sizeof cA);
+    const bool shield_on = SHIELDED && live && v.hist_len >= 2;  // gate safe_controller.py:232-239
+    if (live) cA = predict<KIND, SHIELDED>(v, v.act_steer, dt);
+    cB = cA;
+    double steerB = v.act_steer;
+    if (SHIELDED) {
+      // LC veto re-steers to the CURRENT lane (decentral_layer.py:501-506,739-744); identical to
+      // the nominal command unless a lane change / lane hand-over is under way or the car crashed
+      if (shield_on && (v.tlane != v.lane || v.crashed)) {
+        steerB = steering_control(v.x, v.y, v.h, v.v, v.lane);
+        cB = predict<KIND, true>(v, steerB, dt);
+      }
+    }
+    double new_acc = v.act_acc, new_steer = v.act_steer;
+    bool use_B = false;
+
+    if (SHIELDED) {
+      if (__any(shield_on)) {
+        // ---------------- front-to-back sweep -------------------------------------------------
+        bool stepped = false;
+        for (int r = 0; r < st.N; r++) {
+          const unsigned sel = group_ballot<G>(shield_on && rank == r, gb);
+          const bool has = sel != 0;
+          const int ai = has ? (__ffs((int)sel) - 1) : 0;
+          const int src = gb + ai;
+          // ego broadcast: position, lane, next lane
+          const double ex = shfl_d(v.x, src), ey = shfl_d(v.y, src);
+          const int epk = shfl_i(v.lane | (nl_self << 4), src);
+          const int elane = epk & 15, enl = epk >> 4;
+          // ---- relation of this lane's vehicle (current state) to the ego (decentral_layer.py:85-211)
+          const bool other = v.present && env_active && has && a != ai;
+          const double dx = v.x - ex, dy = v.y - ey;
+          const bool close = other && sqrt(dx * dx + dy * dy) < kPerception;
+          const double esx = lane_sx(elane);
+          const double ld = (v.x - esx) - (ex - esx);  // ego.lane_distance_to(veh)
+          const double key = close ? fabs(ld) : INFINITY;
+          int pos = 0;  // index in close_vehicles_to(...) (road.py:257-267), count = 5
+#pragma unroll
+          for (int m = 1; m < G; m++) {
+            double kp = shflx_d(key, m);
+            pos += (kp < key || (kp == key && (a ^ m) < a)) ? 1 : 0;
+          }
+          const bool in5 = close && pos < 5;
+          const int v_a = adj_lane(elane, enl, v.lane);
+          const int a_v = adj_lane(v.lane, nl_self, elane);
+          const bool appr = !(ld < 0) && fabs(dy) <= 3.5 && (dy < 0 ? v.h > 0.037 : v.h < -0.037);  // :46-57
+          const bool adj = !appr && (v_a != 0 || a_v != 0);
+          const bool same = (elane == v.lane) || (v.lane == enl);  // is_same_lane :15-20
+          const bool c_oar = in5 && adj && ld < 0;
+          const bool c_oa = in5 && adj && ld >= 0;
+          const bool c_ol = in5 && !adj && (same || appr) && ld > 0;
+          const bool use_left = (v_a == -1 || a_v == 1);  // :146-152 which front corner of veh
+          const unsigned cflag = (use_left ? offL : offR) ? 1u : 0u;
+          const unsigned none = 0x3FFu;
+          unsigned f_ol = c_ol ? ((unsigned)pos << 5 | (unsigned)a << 1) : none;
+          unsigned f_oa = c_oa ? ((unsigned)pos << 5 | (unsigned)a << 1 | cflag) : none;
+          unsigned f_oar = c_oar ? ((unsigned)pos << 5 | (unsigned)a << 1) : none;
+          unsigned w = f_ol | f_oa << 10 | f_oar << 20;
+#pragma unroll
+          for (int m = 1; m < G; m <<= 1) {
+            unsigned o = (unsigned)shflx_i((int)w, m);
+            unsigned m0 = min(w & 0x3FFu, o & 0x3FFu), m1 = min((w >> 10) & 0x3FFu, (o >> 10) & 0x3FFu),
+                     m2 = min((w >> 20) & 0x3FFu, (o >> 20) & 0x3FFu);
+            w = m0 | m1 << 10 | m2 << 20;
+          }
+          f_ol = w & 0x3FFu; f_oa = (w >> 10) & 0x3FFu; f_oar = (w >> 20) & 0x3FFu;
+          bool has_ol = f_ol != none, has_oa = f_oa != none;
+          const bool has_oar = f_oar != none;
+          const int s_ol = gb + (has_ol ? (int)((f_ol >> 1) & 15u) : 0);
+          const int s_oa = gb + (has_oa ? (int)((f_oa >> 1) & 15u) : 0);
+          const int s_oar = gb + (has_oar ? (int)((f_oar >> 1) & 15u) : 0);
+          // s_ol / s_oa = veh.state_hist[-2] (x, vx); MASS adds veh.safe_action, veh.fg_params["g"]
+          double ol_x = shfl_d(v.h2x, s_ol), ol_vx = shfl_d(v.h2vx, s_ol);
+          double oa_x = shfl_d(v.h2x, s_oa), oa_vx = shfl_d(v.h2vx, s_oa);
+          double ol_acc = 0, ol_g = 0, oa_acc = 0, oa_g = 0;
+          if (MASS) {
+            ol_acc = shfl_d(v.safe_acc, s_ol); ol_g = shfl_d(v.gvx, s_ol);
+            oa_acc = shfl_d(v.safe_acc, s_oa); oa_g = shfl_d(v.gvx, s_oa);
+          }
+          // s_oar = veh.to_dict(): current x and vx = speed*cos(heading)
+          const double oar_x = shfl_d(v.x, s_oar), oar_vx = shfl_d(v.v * cpsi, s_oar);
+          bool constrain_adj = MASS && has_oa && (f_oa & 1u);
+          if (!has_ol) { ol_acc = 0; ol_g = 0; }  // defaults a_ol / gp["ol"] (:93-95)
+          if (!has_oa) { oa_acc = 0; oa_g = 0; }
+          if (!MASS) { ol_acc = kCbfAccLo; oa_acc = kCbfAccLo; }  // worst-case leader braking :473
+          // ---- from here on every lane acts as "ego" on its own registers; only lane ai commits
+          // obstacle at (420, 4) as leader / adjacent (:213-246)
+          if (!(v.x > kObstX)) {
+            const double ady = fabs(kObstY - v.y);
+            if ((!has_ol || kObstX <= ol_x) && ady <= 2) {
+              has_ol = true; ol_x = kObstX; ol_vx = 0.0;
+              if (MASS) { ol_acc = 0; ol_g = 0; }
+            }
+            if ((!has_oa || kObstX <= oa_x) && (2 < ady && ady <= 4)) {
+              has_oa = true; oa_x = kObstX; oa_vx = 0.0;
+              if (MASS) { oa_acc = 0; oa_g = 0; constrain_adj = false; }
+            }
+          }
+          // safe_action_hss / safe_action_mass (:290-518 / :521-764), scalar form of the 8-vectors
+          double v_min = v.v + kLcMinAcc * dt;
+          if (MASS) v_min = v_min > 0 ? v_min : 0;  // :798
+          const double v_max = v.v + kLcMaxAcc * dt;
+          double evx = v.v * cpsi;
+          evx = evx > 1 ? evx : 1;  // :307-309
+          const double x_e = v.x;
+          const double x_ol = has_ol ? ol_x : x_e + kPerception + 1;
+          const double x_oa = has_oa ? oa_x : x_e + kPerception + 1;
+          const double x_oar = has_oar ? oar_x : x_e - kPerception - 1;
+          const double g0 = v.gvx * dt;
+          const double g2 = MASS ? ol_g * dt : 1 * dt;
+          const double g4 = MASS ? oa_g * dt : 1 * dt;
+          const double g6 = 1 * dt;
+          double sv_oar = has_oar ? oar_vx : 0;
+          sv_oar = sv_oar + kCbfAccHi * dt;
+          sv_oar = sv_oar > 1 ? sv_oar : 1;
+          const double buffer = (kCbfAccHi + 0.1) * dt * c.tau;
+          const double sd0 = evx * c.tau + kVehLength + buffer;
+          const double sd2 = sv_oar * c.tau + kVehLength + buffer;
+          // simplified_control (:60-77): only the speed components enter the CBF rows
+          double u0 = evx + v.act_acc * dt; u0 = u0 > 0 ? u0 : 0;
+          double u2 = 0, u4 = 0, u6 = 0;
+          if (has_ol) { u2 = ol_vx + ol_acc * dt; u2 = u2 > 0 ? u2 : 0; }
+          if (has_oa) { u4 = oa_vx + oa_acc * dt; u4 = u4 > 0 ? u4 : 0; }
+          if (has_oar) { u6 = oar_vx + kCbfAccHi * dt; u6 = u6 > 0 ? u6 : 0; }
+          // cbf.py:262-322, :374-422
+          const double eta = c.eta;
+          const double q_lon = -kVehLength - sd0;
+          double q_lona = -kVehLength - sd0;
+          const double q_lonr = -kVehLength - sd2;
+          if (MASS && constrain_adj) q_lona = -kVehLength - sd0 - kAdjBuffer;
+          const double px_lon = x_ol - x_e, px_lona = x_oa - x_e, px_lonr = x_e - x_oar;
+          const double h0 = px_lon + (eta - 1) * px_lon + eta * q_lon + (-(g0 * u0) + g2 * u2);
+          const double h1 = v_max - u0;
+          const double h2 = -v_min + u0;
+          double h3 = __builtin_nan(""), hc = h0;
+          if (MASS && constrain_adj) {
+            h3 = px_lona + (eta - 1) * px_lona + eta * q_lona + (-(g0 * u0) + g4 * u4);
+            hc = h3 < h0 ? h3 : h0;
+          }
+          // exact KKT point of min 1/2(d^2 + e^2 + 1e18 s^2) s.t. a d - s <= hc, lo <= d <= hi
+          double d;
+          if (g0 > 0) d = fmin(0.0, hc / g0);
+          else if (g0 < 0) d = fmax(0.0, hc / g0);
+          else d = 0.0;
+          d = fmin(fmax(d, -h2), h1);
+          double us0 = u0 + d;
+          // is_lc_allowed (cbf.py:324-339) with u = [u_safe0, steer, u2.., u6..]
+          const double hls_lona = px_lona + q_lona;
+          const double hlds_lona = px_lona + ((-g0) * us0 + g4 * u4) + q_lona;
+          const double hls_lonr = px_lonr + q_lonr;
+          const double hlds_lonr = px_lonr + (g0 * us0 + (-g6) * u6) + q_lonr;
+          const bool lc_allowed = ((hls_lona >= 0) && (hlds_lona + (eta - 1) * hls_lona) >= 0) &&
+                                  ((hls_lonr >= 0) && (hlds_lonr + (eta - 1) * hls_lonr) >= 0);
+          bool veto;
+          int fl = v.flags & MM_FLAG_COLLABORATE_ADJ;
+          if (constrain_adj) fl |= MM_FLAG_IS_COLLABORATING;
+          if (!MASS) {
+            veto = !lc_allowed;
+          } else {
+            const bool can_abort_lc = !offL && !offR;  // :728-736 on the pre-step pose
+            veto = can_abort_lc && !lc_allowed;
+            if (!veto && (v.hl == 2 || v.hl == 0) && v.v < kStoppingSpeed) us0 = u0;  // :746-750
+            if ((hlds_lona + (eta - 1) * hls_lona) >= -1e-6) fl |= MM_FLAG_COLLABORATE_ADJ;  // cbf.py:424-430
+            else fl &= ~MM_FLAG_COLLABORATE_ADJ;
+          }
+          if (!veto) fl |= MM_FLAG_IS_LC_SAFE;
+          if (has && a == ai && shield_on) {
+            new_acc = (us0 - evx) / dt;  // derived_acceleration :80-82
+            use_B = veto;
+            new_steer = veto ? steerB : v.act_steer;
+            if (veto) v.tlane = v.lane;
+            v.flags = fl;
+            qt.rows = (MASS && constrain_adj) ? 4 : 3; qt.a = g0; qt.h0 = h0; qt.h1 = h1; qt.h2 = h2;
+            qt.h3 = h3; qt.d = d;
+            // commit Vehicle.step now: followers must see this vehicle's post-step state
+            const Cand &cc = use_B ? cB : cA;
+            double nv = v.v + new_acc * dt;
+            nv = nv > 0 ? nv : 0;
+            v.safe_steer = new_steer; v.safe_acc = new_acc;
+            v.x = cc.x; v.y = cc.y; v.h = cc.h; v.v = nv; v.gvx = cc.gvx; v.lane = cc.lane;
+            cpsi = cc.cpsi; offL = cc.offL; offR = cc.offR;
+            nl_self = next_lane(v.lane, v.x, v.y);
+            v.h2x = v.h1x; v.h2h = v.h1h; v.h2vx = v.h1vx; v.h2v = v.h1v;  // log_step :187-201
+            v.h1x = v.x; v.h1h = v.h; v.h1vx = v.v * cpsi; v.h1v = v.v;
+            stepped = true;
+          }
+        }
+        // vehicles whose shield is still gated (first two sub-steps of an episode) step unshielded
+        if (live && !stepped) {
+          double nv = v.v + v.act_acc * dt;
+          nv = nv > 0 ? nv : 0;
+          v.safe_steer = v.act_steer; v.safe_acc = v.act_acc;
+          v.x = cA.x; v.y = cA.y; v.h = cA.h; v.v = nv; v.gvx = cA.gvx; v.lane = cA.lane;
+          cpsi = cA.cpsi; offL = cA.offL; offR = cA.offR;
+          nl_self = next_lane(v.lane, v.x, v.y);
+          v.h2x = v.h1x; v.h2h = v.h1h; v.h2vx = v.h1vx; v.h2v = v.h1v;
+          v.h1x = v.x; v.h1h = v.h; v.h1vx = v.v * cpsi; v.h1v = v.v;
+          if (v.hist_len < 2) v.hist_len++;
+        }
+      } else if (live) {
+        double nv = v.v + v.act_acc * dt;
+        nv = nv > 0 ? nv : 0;
+        v.safe_steer = v.act_steer; v.safe_acc = v.act_acc;
+        v.x = cA.x; v.y = cA.y; v.h = cA.h; v.v = nv; v.gvx = cA.gvx; v.lane = cA.lane;
+        cpsi = cA.cpsi; offL = cA.offL; offR = cA.offR;
+        nl_self = next_lane(v.lane, v.x, v.y);
+        v.h2x = v.h1x; v.h2h = v.h1h; v.h2vx = v.h1vx; v.h2v = v.h1v;
+        v.h1x = v.x; v.h1h = v.h; v.h1vx = v.v * cpsi; v.h1v = v.v;
+        if (v.hist_len < 2) v.hist_len++;
+      }
+    } else if (live) {
+      // unshielded Vehicle.step / MDPLCVehicle.step: every vehicle integrates independently
+      double nv = v.v + v.act_acc * dt;
+      nv = nv > 0 ? nv : 0;
+      v.x = cA.x; v.y = cA.y; v.h = cA.h; v.v = nv; v.lane = cA.lane;
+      if (LC) {
+        v.safe_steer = v.act_steer; v.safe_acc = v.act_acc; v.gvx = cA.gvx;
+        v.h2x = v.h1x; v.h2h = v.h1h; v.h2vx = v.h1vx; v.h2v = v.h1v;
+        v.h1x = v.x; v.h1h = v.h; v.h1vx = v.v * cA.cpsi; v.h1v = v.v;
+        if (v.hist_len < 2) v.hist_len++;
+      }
+    }
+
+    // ---------------- collisions (road.py:288-292, kinematics.py:175-209) ----------------------
+    unsigned hits = 0;
+#pragma unroll
+    for (int m = 1; m < G; m++) {
+      double px = shflx_d(v.x, m), py = shflx_d(v.y, m), ph = shflx_d(v.h, m);
+      bool pp = shflx_i((int)(v.present && env_active), m) != 0;
+      double dx = px - v.x, dy = py - v.y;
+      if (live && pp && !(sqrt(dx * dx + dy * dy) > kVehLength))
+        if (rects_intersect(v.x, v.y, v.h, px, py, kVehLength, kVehWidth, ph)) hits |= 1u << (a ^ m);
+    }
+    bool obst_hit = false;
+    if (live) {
+      double dx = kObstX - v.x, dy = kObstY - v.y;
+      if (!(sqrt(dx * dx + dy * dy) > kVehLength)) obst_hit = rects_intersect(v.x, v.y, v.h, kObstX, kObstY, 2.0, 2.0, 0.0);
+    }
+    if (__any(hits != 0 || obst_hit)) {
+      // order-dependent part: creation-order double loop, min-|speed| hand-down (kinematics.py:187-196)
+      unsigned cb = group_ballot<G>(v.crashed != 0, gb);
+      const unsigned ob = group_ballot<G>(obst_hit, gb);
+      for (int ii = 0; ii < st.N; ii++) {
+        const unsigned row = (unsigned)shfl_i((int)hits, gb + ii);
+        for (int jj = 0; jj < st.N; jj++) {
+          const double si = shfl_d(v.v, gb + ii), sj = shfl_d(v.v, gb + jj);
+          const bool fire = !((cb >> ii) & 1u) && ii != jj && ((row >> jj) & 1u);
+          if (fire) {
+            const double s = fabs(si) <= fabs(sj) ? si : sj;
+            if (a == ii || a == jj) { v.v = s; v.crashed = 1; }
+            cb |= (1u << ii) | (1u << jj);
+          }
+        }
+        if (!((cb >> ii) & 1u) && ((ob >> ii) & 1u)) {
+          if (a == ii) { v.v = fabs(v.v) <= 0 ? v.v : 0.0; v.crashed = 1; }
+          cb |= 1u << ii;
+        }
+      }
+    }
+    if (env_active) time += 1;
+    if (out.trace && live) {
+      double *t = out.trace + (long long)k * MM_T_COUNT * A + i;
+      t[MM_T_X * A] = v.x; t[MM_T_Y * A] = v.y; t[MM_T_HEADING * A] = v.h; t[MM_T_SPEED * A] = v.v;
+      t[MM_T_ACT_STEER * A] = v.act_steer; t[MM_T_ACT_ACC * A] = v.act_acc;
+      t[MM_T_SAFE_STEER * A] = LC ? v.safe_steer : v.act_steer;
+      t[MM_T_SAFE_ACC * A] = LC ? v.safe_acc : v.act_acc;
+      t[MM_T_LANE * A] = v.lane; t[MM_T_TARGET_LANE * A] = v.tlane; t[MM_T_CRASHED * A] = v.crashed;
+      t[MM_T_FLAGS * A] = v.flags; t[MM_T_QP_ROWS * A] = qt.rows; t[MM_T_QP_A * A] = qt.a;
+      t[MM_T_QP_H0 * A] = qt.h0; t[MM_T_QP_H1 * A] = qt.h1; t[MM_T_QP_H2 * A] = qt.h2;
+      t[MM_T_QP_H3 * A] = qt.h3; t[MM_T_QP_D * A] = qt.d;
+    }
+    // _is_terminal (merge_env_v1.py:168-172) breaks the sub-step loop (abstract.py:530)
+    const bool term = group_ballot<G>(v.present && (v.crashed || v.x < 0), gb) != 0 || steps >= c.T;
+    if (term) env_active = false;
+    (void)new_steer;
+  }
+
+  // ---------------- rewards / info (merge_env_v1.py:59-166, abstract.py:469-498) -----------------
+  const bool env_ok = n_veh > 0;
+  const unsigned crashed_bits = group_ballot<G>(v.present && v.crashed, gb);
+  const bool done = env_ok && (crashed_bits != 0 || steps >= c.T ||
+                               group_ballot<G>(v.present && v.x < 0, gb) != 0);
+  const int nl = v.present ? next_lane(v.lane, v.x, v.y) : 0;
+  // surrounding_vehicles lane sets (road.py:315-342), as bit sets over lane ids
+  const unsigned allow_tbl[6] = {
+      (1u << MM_LANE_AB0) | (1u << MM_LANE_BC0), (1u << MM_LANE_AB0) | (1u << MM_LANE_BC0) | (1u << MM_LANE_CD0),
+      (1u << MM_LANE_KB0) | (1u << MM_LANE_BC1), (1u << MM_LANE_BC0) | (1u << MM_LANE_CD0),
+      (1u << MM_LANE_JK0) | (1u << MM_LANE_KB0), (1u << MM_LANE_JK0) | (1u << MM_LANE_KB0) | (1u << MM_LANE_BC1)};
+  unsigned allow_own = 0, allow_side = 0;
+  {
+    int side = -1;  // _regional_reward side / ramp lane choice (merge_env_v1.py:95-118)
+    const int l = v.lane;
+    if (l == MM_LANE_BC0) side = MM_LANE_BC1;
+    else if (l == MM_LANE_AB0 && v.x > 220) side = MM_LANE_KB0;
+    else if (l == MM_LANE_BC1) side = MM_LANE_BC0;
+    else if (l == MM_LANE_KB0) side = MM_LANE_AB0;
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+      if (l == q) allow_own = allow_tbl[q];
+      if (side == q) allow_side = allow_tbl[q];
+    }
+  }
+  double hd = 60;  // _compute_headway_distance abstract.py:620-635
+  double of_s = 0, or_s = 0, sf_s = 0, sr_s = 0;
+  int of_i = -1, or_i = -1, sf_i = -1, sr_i = -1;  // own/side chain front & rear
+#pragma unroll
+  for (int m = 1; m < G; m++) {
+    const int p = a ^ m;
+    double px = shflx_d(v.x, m);
+    int pk = shflx_i(v.present ? v.lane : 15, m);
+    bool pp = pk != 15;
+    if (pp && pk == v.lane && px > v.x) { double dd = px - v.x; if (dd < hd) hd = dd; }
+    if (pp && v.lane != MM_LANE_BC1 && pk == nl && px > v.x) { double dd = px - v.x; if (dd < hd) hd = dd; }
+    const bool in_own = pp && ((allow_own >> pk) & 1u), in_side = pp && ((allow_side >> pk) & 1u);
+    // road.py:344-349: front = min s_v >= s (ties: later index), rear = max s_v < s (ties: earlier)
+    if (in_own && v.x <= px && (of_i < 0 || px < of_s || (px == of_s && p > of_i))) { of_s = px; of_i = p; }
+    if (in_own && px < v.x && (or_i < 0 || px > or_s || (px == or_s && p < or_i))) { or_s = px; or_i = p; }
+    if (in_side && v.x <= px && (sf_i < 0 || px < sf_s || (px == sf_s && p > sf_i))) { sf_s = px; sf_i = p; }
+    if (in_side && px < v.x && (sr_i < 0 || px > sr_s || (px == sr_s && p < sr_i))) { sr_s = px; sr_i = p; }
+  }
+  // _agent_reward merge_env_v1.py:64-89
+  double local = 0;
+  if (v.present) {
+    double scaled = 0 + (v.v - c.rs_lo) * (1 - 0) / (c.rs_hi - c.rs_lo);
+    double merging = 0;
+    if (v.lane == MM_LANE_BC1) { double t = v.x - 420; merging = -exp(-(t * t) / (10 * 100)); }
+    double hc = v.v > 0 ? log(hd / (c.headway_time * v.v)) : 0;
+    local = c.collision_reward * (-1 * v.crashed) + (c.high_speed_reward * clipd(scaled, 0, 1)) +
+            c.merging_lane_cost * merging + c.headway_cost * (hc < 0 ? hc : 0);
+  }
+  // regional reward: mean over [v_fl, v_fr, self, v_rl, v_rr] (merge_env_v1.py:119-124)
+  double regional = 0;
+  {
+    const bool on_main = v.lane == MM_LANE_AB0 || v.lane == MM_LANE_BC0 || v.lane == MM_LANE_CD0;
+    const int i_fl = on_main ? of_i : sf_i, i_rl = on_main ? or_i : sr_i;
+    const int i_fr = on_main ? sf_i : of_i, i_rr = on_main ? sr_i : or_i;
+    const double r_fl = shfl_d(local, gb + (i_fl < 0 ? 0 : i_fl)), r_fr = shfl_d(local, gb + (i_fr < 0 ? 0 : i_fr));
+    const double r_rl = shfl_d(local, gb + (i_rl < 0 ? 0 : i_rl)), r_rr = shfl_d(local, gb + (i_rr < 0 ? 0 : i_rr));
+    double sum = 0;
+    int cnt = 0;
+    if (i_fl >= 0) { sum += r_fl; cnt++; }
+    if (i_fr >= 0) { sum += r_fr; cnt++; }
+    sum += local; cnt++;
+    if (i_rl >= 0) { sum += r_rl; cnt++; }
+    if (i_rr >= 0) { sum += r_rr; cnt++; }
+    regional = sum / cnt;
+  }
+  // env-level sums in creation order (Python sum / += order)
+  double rsum = 0, ssum = 0;
+  for (int q = 0; q < st.N; q++) {
+    const double lr = shfl_d(local, gb + q), sp = shfl_d(v.v, gb + q);
+    if ((present_bits >> q) & 1u) { rsum += lr; ssum += sp; }
+  }
+  const double reward = env_ok ? rsum / n_veh : 0, avg_speed = env_ok ? ssum / n_veh : 0;
+  // _compute_min_time_headway merge_env_v1.py:373-386
+  double th = INFINITY;
+  if (v.present) {
+    double h2d = hd;
+    if (fabs(kObstY - v.y) <= 2 && kObstX > v.x) { double dd = kObstX - v.x; if (dd < h2d) h2d = dd; }
+    h2d = h2d - kVehLength;
+    double vx = v.v * cos(v.h);
+    th = h2d / (vx > 1 ? vx : 1);
+  }
+  const double min_headway = group_min_d<G>(th);
+  double merge_pct = __builtin_nan("");
+  if (done) {
+    const int n_rem = __popc(group_ballot<G>(
+        v.present && (v.lane == MM_LANE_BC1 || v.lane == MM_LANE_KB0 || v.lane == MM_LANE_JK0), gb));
+    merge_pct = n_merge > 0 ? (double)(n_merge - n_rem) / n_merge * 100 : 100.0;
+  }
+  if (valid) {
+    if (out.agents_rewards) out.agents_rewards[i] = v.present ? local : 0;
+    if (out.regional_rewards) out.regional_rewards[i] = v.present ? regional : 0;
+    if (out.agents_dones) out.agents_dones[i] = v.present ? (uint8_t)(v.crashed || steps >= c.T || v.x < 0) : 1;
+    if (out.crashed) out.crashed[i] = v.present ? (uint8_t)v.crashed : 0;
+    if (out.agents_info) {
+      out.agents_info[i * 3 + 0] = v.present ? v.x : 0;
+      out.agents_info[i * 3 + 1] = v.present ? v.y : 0;
+      out.agents_info[i * 3 + 2] = v.present ? v.v : 0;
+    }
+  }
+  if (e < st.E && a == 0 && env_ok) {
+    if (out.reward) out.reward[e] = reward;
+    if (out.done) out.done[e] = (uint8_t)done;
+    if (out.average_speed) out.average_speed[e] = avg_speed;
+    if (out.traffic_speed) out.traffic_speed[e] = avg_speed;  // CAV-only traffic: road.vehicles == controlled
+    if (out.min_headway) out.min_headway[e] = min_headway;
+    if (out.merge_percent) out.merge_percent[e] = merge_pct;
+  }
+  // ---------------- rollout metrics: block partial sums, one atomic per block ---------
+  if (metrics) {
+    __shared__ double s_m[8];
+    if (threadIdx.x < 8) s_m[threadIdx.x] = threadIdx.x == 7 ? INFINITY : 0.0;
+    __syncthreads();
+    if (e < st.E && a == 0 && env_ok) {
+      atomicAdd(&s_m[0], reward); atomicAdd(&s_m[2], avg_speed); atomicAdd(&s_m[3], avg_speed);
+      atomicAdd(&s_m[4], 1.0);
+      if (done) { atomicAdd(&s_m[1], crashed_bits ? 1.0 : 0.0); atomicAdd(&s_m[5], merge_pct); atomicAdd(&s_m[6], 1.0); }
+      atomic_min_d(&s_m[7], min_headway);
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) atomicAdd(&metrics[threadIdx.x], s_m[threadIdx.x]);
+    if (threadIdx.x == 7) atomic_min_d(&metrics[7], s_m[7]);
+  }
+  // ---------------- optional re-spawn (marl/mappo.py:133-135 `if done: env.reset()`) --------------
+  if (c.auto_reset && done) {
+    const uint64_t seed = st.seeds[e];
+    Veh nv;
+    memset(&nv, 0, sizeof nv);
+    int nm = 0;
+    if (valid && v.present) nm = spawn_vehicle(nv, a, n_veh, seed, (uint32_t)episode);
+    if (valid && v.present) v = nv;
+    n_merge = shfl_i(nm, gb);
+    steps = 0; time = 0; episode += 1;
+  }
+  if (valid && v.present) store_veh(st, i, v);
+  if (e < st.E && a == 0) {
+    st.I[MM_E_STEPS * st.E + e] = steps; st.I[MM_E_TIME * st.E + e] = time;
+    st.I[MM_E_N_MERGE * st.E + e] = n_merge; st.I[MM_E_EPISODE * st.E + e] = episode;
+  }
+  observe<G, KIND, OBS_T>(c, v, a, gb, i, valid, (OBS_T *)out.obs, out.action_mask);
+}
+
+// reset / init / observe --------------------------------------------------------------------------
+// mode 0: device-RNG spawn (mm_reset), 1: finish a host-provided spawn (mm_init_from_kinematics),
+// 2: observe only (mm_observe)
+template <int G, int KIND, typename OBS_T>
+__global__ __launch_bounds__(256) void reset_kernel(DevCfg c, DevState st, int mode, const uint8_t *env_mask,
+                                                    const uint64_t *seeds_in, OBS_T *obs, uint8_t *avail) {
+  const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e = gtid / G;
+  const int a = (int)(gtid % G);
+  const int gb = lane_id() & ~(G - 1);
+  const bool valid = e < st.E && a < st.N;
+  const long long i = e * st.N + a;
+  const bool selected = e < st.E && mode != 2 && (!env_mask || env_mask[e]);
+  Veh v;
+  load_veh(st, i, valid, v);
+  if (selected) {
+    int steps = 0, time = 0, n_merge = 0, episode = st.I[MM_E_EPISODE * st.E + e];
+    if (mode == 0) {
+      if (seeds_in && a == 0) st.seeds[e] = seeds_in[e];
+      const uint64_t seed = seeds_in ? seeds_in[e] : st.seeds[e];
+      int nm = 0;
+      if (valid) { nm = spawn_vehicle(v, a, st.N, seed, (uint32_t)episode); st.B[MM_B_KIND * st.A + i] = 1; }
+      n_merge = shfl_i(nm, gb);
+      episode += 1;
+    } else {
+      if (valid && v.present) init_vehicle(v);
+      n_merge = __popc(group_ballot<G>(valid && v.present && (v.lane == MM_LANE_JK0 || v.lane == MM_LANE_KB0), gb));
+    }
+    if (valid && v.present) store_veh(st, i, v);
+    if (a == 0) {
+      st.I[MM_E_STEPS * st.E + e] = steps; st.I[MM_E_TIME * st.E + e] = time;
+      st.I[MM_E_N_MERGE * st.E + e] = n_merge; st.I[MM_E_EPISODE * st.E + e] = episode;
+    }
+  } else if (e < st.E && mode == 0 && env_mask) {
+    (void)0;  // untouched env: only re-observed below
+  }
+  observe<G, KIND, OBS_T>(c, v, a, gb, i, valid, obs, avail);
+}
+
+// stand-alone batched shield QP (cbf.py:110-161): exact KKT point, one thread per QP
+__global__ void qp_kernel(int n, const double *__restrict__ G, const double *__restrict__ h,
+                          const int32_t *__restrict__ rows, double *__restrict__ u, uint8_t *status) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double a = G[(long long)k * 12], *hh = h + (long long)k * 4;
+  double hc = hh[0];
+  if (rows[k] == 4 && hh[3] < hc) hc = hh[3];
+  double d;
+  if (a > 0) d = fmin(0.0, hc / a);
+  else if (a < 0) d = fmax(0.0, hc / a);
+  else d = 0.0;
+  d = fmin(fmax(d, -hh[2]), hh[1]);
+  const double s = a * d - hc;
+  u[k * 3 + 0] = d; u[k * 3 + 1] = 0.0; u[k * 3 + 2] = s > 0 ? s : 0.0;
+  if (status) status[k] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: C ABI
+// ------------------------------------------------------------------------------------------------
+struct MMHandle_ {
+  MMConfig cfg;
+  int E, N, device;
+  unsigned char *state;
+  MMStateLayout lay;
+  long long first_env;
+  double *metrics;
+  char err[256];
+};
+
+static uint64_t align256(uint64_t x) { return (x + 255u) & ~(uint64_t)255u; }
+
+extern "C" int32_t mm_abi_version(void) { return MM_ABI_VERSION; }
+
+extern "C" int32_t mm_state_layout(int32_t E, int32_t N, MMStateLayout *out) {
+  if (!out || E <= 0 || N <= 0 || N > MM_MAX_AGENTS) return MM_ERR_INVALID_ARG;
+  uint64_t A = (uint64_t)E * (uint64_t)N, off = 0;
+  out->f64_offset = off; off = align256(off + A * 8u * MM_F_COUNT);
+  out->u8_offset = off; off = align256(off + A * MM_B_COUNT);
+  out->env_offset = off; off = align256(off + (uint64_t)E * 4u * MM_E_COUNT);
+  out->seed_offset = off; off = align256(off + (uint64_t)E * 8u);
+  out->total_bytes = off;
+  return MM_OK;
+}
+
+static int check_cfg(const MMConfig *c, int N, char *err) {
+  if (!c || c->abi_version != MM_ABI_VERSION) { snprintf(err, 256, "ABI version mismatch"); return MM_ERR_INVALID_ARG; }
+  if (c->env_kind != MM_ENV_V0 && c->env_kind != MM_ENV_V1) { snprintf(err, 256, "unknown env_kind %d", c->env_kind); return MM_ERR_INVALID_ARG; }
+  if (c->shield < MM_SHIELD_NONE || c->shield > MM_SHIELD_MASS) { snprintf(err, 256, "Undefined safety_type:%d", c->shield); return MM_ERR_INVALID_ARG; }
+  if (c->policy_frequency <= 0 || c->simulation_frequency < c->policy_frequency ||
+      c->simulation_frequency / c->policy_frequency > 3) { snprintf(err, 256, "unsupported frequencies"); return MM_ERR_INVALID_ARG; }
+  if (N > 12) { snprintf(err, 256, "N=%d exceeds the 6+6 spawn slots", N); return MM_ERR_INVALID_ARG; }
+  return MM_OK;
+}
+
+static int hip_fail(MMHandle h, hipError_t e, const char *what) {
+  snprintf(h->err, sizeof h->err, "%s: %s", what, hipGetErrorString(e));
+  return MM_ERR_DEVICE;
+}
+
+extern "C" int32_t mm_create(const MMConfig *cfg, int32_t E, int32_t N, int32_t device, void *state,
+                             uint64_t state_bytes, int64_t first_env, MMHandle *out) {
+  if (!out || !state) return MM_ERR_INVALID_ARG;
+  MMHandle h = (MMHandle)calloc(1, sizeof(struct MMHandle_));
+  if (mm_state_layout(E, N, &h->lay) != MM_OK || state_bytes < h->lay.total_bytes ||
+      ((uintptr_t)state & 255u) || check_cfg(cfg, N, h->err) != MM_OK) {
+    free(h);
+    return MM_ERR_INVALID_ARG;
+  }
+  h->cfg = *cfg; h->E = E; h->N = N; h->device = device; h->state = (unsigned char *)state;
+  h->first_env = first_env;
+  // per-env seed plane: cfg.seed + global env index
+  uint64_t *tmp = (uint64_t *)malloc((size_t)E * 8u);
+  for (int64_t e = 0; e < E; e++) tmp[e] = cfg->seed + (uint64_t)(first_env + e);
+  hipError_t rc = hipSetDevice(device);
+  if (rc == hipSuccess) rc = hipMemcpy(h->state + h->lay.seed_offset, tmp, (size_t)E * 8u, hipMemcpyHostToDevice);
+  free(tmp);
+  if (rc != hipSuccess) { free(h); return MM_ERR_DEVICE; }
+  *out = h;
+  return MM_OK;
+}
+extern "C" int32_t mm_destroy(MMHandle h) { free(h); return MM_OK; }
+extern "C" int32_t mm_set_config(MMHandle h, const MMConfig *cfg) {
+  if (!h) return MM_ERR_INVALID_ARG;
+  int rc = check_cfg(cfg, h->N, h->err);
+  if (rc == MM_OK) h->cfg = *cfg;
+  return rc;
+}
+extern "C" int32_t mm_set_metrics_buffer(MMHandle h, double *metrics) {
+  if (!h) return MM_ERR_INVALID_ARG;
+  h->metrics = metrics;
+  return MM_OK;
+}
+extern "C" const char *mm_last_error(MMHandle h) { return h ? h->err : "null handle"; }
+
+static DevCfg dev_cfg(const MMHandle h) {
+  const MMConfig &c = h->cfg;
+  DevCfg d;
+  d.env_kind = c.env_kind; d.shield = c.env_kind == MM_ENV_V1 ? c.shield : MM_SHIELD_NONE;
+  d.nsub = c.simulation_frequency / c.policy_frequency; d.T = c.duration * c.policy_frequency;
+  d.action_masking = c.action_masking; d.auto_reset = c.auto_reset; d.obs_f64 = c.obs_f64; d.N = h->N;
+  d.dt = 1.0 / c.simulation_frequency;
+  d.collision_reward = c.collision_reward; d.high_speed_reward = c.high_speed_reward;
+  d.headway_cost = c.headway_cost; d.headway_time = c.headway_time; d.merging_lane_cost = c.merging_lane_cost;
+  d.rs_lo = c.reward_speed_lo; d.rs_hi = c.reward_speed_hi; d.eta = c.cbf_eta; d.tau = c.cbf_tau;
+  return d;
+}
+static DevState dev_state(const MMHandle h) {
+  DevState s;
+  s.F = (double *)(h->state + h->lay.f64_offset); s.B = h->state + h->lay.u8_offset;
+  s.I = (int32_t *)(h->state + h->lay.env_offset); s.seeds = (uint64_t *)(h->state + h->lay.seed_offset);
+  s.A = (long long)h->E * h->N; s.E = h->E; s.N = h->N;
+  return s;
+}
+static int group_size(int N) { return N <= 2 ? 2 : (N <= 4 ? 4 : (N <= 8 ? 8 : 16)); }
+
+template <int G, int KIND, typename OBS_T>
+static void launch_reset_t(MMHandle h, int mode, const uint8_t *mask, const uint64_t *seeds, void *obs,
+                           uint8_t *avail, hipStream_t s) {
+  const long long threads = (long long)h->E * G;
+  const unsigned grid = (unsigned)((threads + 255) / 256);
+  hipLaunchKernelGGL((reset_kernel<G, KIND, OBS_T>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), mode,
+                     mask, seeds, (OBS_T *)obs, avail);
+}
+template <int G>
+static void launch_reset_g(MMHandle h, int mode, const uint8_t *mask, const uint64_t *seeds, void *obs,
+                           uint8_t *avail, hipStream_t s) {
+  const bool v1 = h->cfg.env_kind == MM_ENV_V1, f64 = h->cfg.obs_f64 != 0;
+  if (v1 && f64) launch_reset_t<G, MM_ENV_V1, double>(h, mode, mask, seeds, obs, avail, s);
+  else if (v1) launch_reset_t<G, MM_ENV_V1, float>(h, mode, mask, seeds, obs, avail, s);
+  else if (f64) launch_reset_t<G, MM_ENV_V0, double>(h, mode, mask, seeds, obs, avail, s);
+  else launch_reset_t<G, MM_ENV_V0, float>(h, mode, mask, seeds, obs, avail, s);
+}
+static int launch_reset(MMHandle h, int mode, const uint8_t *mask, const uint64_t *seeds, void *obs,
+                        uint8_t *avail, MMStream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  switch (group_size(h->N)) {
+    case 2: launch_reset_g<2>(h, mode, mask, seeds, obs, avail, s); break;
+    case 4: launch_reset_g<4>(h, mode, mask, seeds, obs, avail, s); break;
+    case 8: launch_reset_g<8>(h, mode, mask, seeds, obs, avail, s); break;
+    default: launch_reset_g<16>(h, mode, mask, seeds, obs, avail, s); break;
+  }
+  hipError_t rc = hipGetLastError();
+  return rc == hipSuccess ? MM_OK : hip_fail(h, rc, "reset launch");
+}
+
+extern "C" int32_t mm_reset(MMHandle h, const uint8_t *env_mask, const uint64_t *seeds, void *obs,
+                            uint8_t *avail, MMStream stream) {
+  if (!h) return MM_ERR_INVALID_ARG;
+  return launch_reset(h, 0, env_mask, seeds, obs, avail, stream);
+}
+extern "C" int32_t mm_init_from_kinematics(MMHandle h, const uint8_t *env_mask, MMStream stream) {
+  if (!h) return MM_ERR_INVALID_ARG;
+  return launch_reset(h, 1, env_mask, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int32_t mm_observe(MMHandle h, void *obs, uint8_t *avail, MMStream stream) {
+  if (!h) return MM_ERR_INVALID_ARG;
+  return launch_reset(h, 2, nullptr, nullptr, obs, avail, stream);
+}
+
+template <int G, int KIND, int SHIELD, typename OBS_T>
+static void launch_step_t(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+  const long long threads = (long long)h->E * G;
+  const unsigned grid = (unsigned)((threads + 255) / 256);
+  hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, OBS_T>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h),
+                     actions, *out, h->metrics);
+}
+template <int G>
+static void launch_step_g(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+  const bool f64 = h->cfg.obs_f64 != 0;
+  if (h->cfg.env_kind == MM_ENV_V0) {
+    if (f64) launch_step_t<G, MM_ENV_V0, MM_SHIELD_NONE, double>(h, actions, out, s);
+    else launch_step_t<G, MM_ENV_V0, MM_SHIELD_NONE, float>(h, actions, out, s);
+    return;
+  }
+  switch (h->cfg.shield) {
+    case MM_SHIELD_HSS:
+      if (f64) launch_step_t<G, MM_ENV_V1, MM_SHIELD_HSS, double>(h, actions, out, s);
+      else launch_step_t<G, MM_ENV_V1, MM_SHIELD_HSS, float>(h, actions, out, s);
+      break;
+    case MM_SHIELD_MASS:
+      if (f64) launch_step_t<G, MM_ENV_V1, MM_SHIELD_MASS, double>(h, actions, out, s);
+      else launch_step_t<G, MM_ENV_V1, MM_SHIELD_MASS, float>(h, actions, out, s);
+      break;
+    default:
+      if (f64) launch_step_t<G, MM_ENV_V1, MM_SHIELD_NONE, double>(h, actions, out, s);
+      else launch_step_t<G, MM_ENV_V1, MM_SHIELD_NONE, float>(h, actions, out, s);
+  }
+}
+
+extern "C" int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStream stream) {
+  if (!h || !actions || !out) return MM_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (out->trace) {
+    // NaN = "sub-step did not run"; 0xFF bytes are a NaN pattern
+    hipError_t rc = hipMemsetAsync(out->trace, 0xFF, (size_t)3 * MM_T_COUNT * h->E * h->N * sizeof(double), s);
+    if (rc != hipSuccess) return hip_fail(h, rc, "trace memset");
+  }
+  switch (group_size(h->N)) {
+    case 2: launch_step_g<2>(h, actions, out, s); break;
+    case 4: launch_step_g<4>(h, actions, out, s); break;
+    case 8: launch_step_g<8>(h, actions, out, s); break;
+    default: launch_step_g<16>(h, actions, out, s); break;
+  }
+  hipError_t rc = hipGetLastError();
+  return rc == hipSuccess ? MM_OK : hip_fail(h, rc, "step launch");
+}
+
+extern "C" int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec, const int32_t *rows,
+                                double *u_out, uint8_t *status, MMStream stream) {
+  if (n <= 0) return MM_OK;
+  hipLaunchKernelGGL(qp_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, G, hvec, rows, u_out,
+                     status);
+  hipError_t rc = hipGetLastError();
+  if (rc != hipSuccess) return h ? hip_fail(h, rc, "qp launch") : MM_ERR_DEVICE;
+  return MM_OK;
+}

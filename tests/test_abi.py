@@ -1,0 +1,71 @@
+"""CPU checks of the drop-in boundary: header <-> ctypes binding <-> exported symbols."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from marl_mass_amd import _cabi as abi
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(REPO, "include", "mm_abi.h")).read()
+
+
+def test_plane_tables_match_header():
+    for prefix, table in (("MM_F_", abi.F_PLANES), ("MM_B_", abi.B_PLANES), ("MM_E_", abi.E_PLANES), ("MM_T_", abi.T_PLANES)):
+        block = re.search(r"enum \{\s*%s[^}]*\}" % prefix, HEADER, re.S).group(0)
+        block = re.sub(r"/\*.*?\*/", "", block, flags=re.S)
+        names = [n for n in re.findall(r"%s([A-Z0-9_]+)" % prefix, block) if n != "COUNT"]
+        dedup = []
+        for n in names:
+            if n not in dedup:
+                dedup.append(n)
+        assert dedup == table, prefix
+
+
+def test_header_declares_every_bound_symbol():
+    for sym in abi.CLib.SYMBOLS:
+        assert re.search(r"\b%s\s*\(" % sym, HEADER), sym
+
+
+@pytest.mark.parametrize("lib", ["marl-mass_amd/csrc/libmm_hip.so", "oracle/libmm_oracle.so"])
+def test_library_exports_abi(lib):
+    """Both implementations load and export every symbol of include/mm_abi.h (no compute calls)."""
+    path = os.path.join(REPO, lib)
+    if not os.path.exists(path):
+        import __graft_entry__
+        __graft_entry__.build()
+    dll = ctypes.CDLL(path)
+    for sym in abi.CLib.SYMBOLS:
+        assert hasattr(dll, sym), (lib, sym)
+    dll.mm_abi_version.restype = ctypes.c_int32
+    assert dll.mm_abi_version() == abi.MM_ABI_VERSION
+    lay = abi.MMStateLayout()
+    dll.mm_state_layout.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(abi.MMStateLayout)]
+    assert dll.mm_state_layout(4096, 8, ctypes.byref(lay)) == 0
+    A = 4096 * 8
+    assert lay.u8_offset >= A * 8 * len(abi.F_PLANES) and lay.total_bytes % 256 == 0
+
+
+def test_struct_sizes():
+    assert ctypes.sizeof(abi.MMConfig) == 10 * 4 + 9 * 8 + 8
+    assert ctypes.sizeof(abi.MMStepOut) == 14 * 8
+
+
+def test_shield_dispatch_strings():
+    """safe_controller.py:229-241 / decentral_layer.py:767-817 string dispatch."""
+    f = abi.shield_from_safety_guarantee
+    assert f("none") == f("priority") == f("dmc") == abi.SHIELD_NONE
+    assert f("cbf-av") == f("cbf-avs") == f("cbf-avs_cint") == f("cbf-hss") == abi.SHIELD_HSS
+    assert f("cbf-cav") == f("cbf-mass") == abi.SHIELD_MASS
+    with pytest.raises(ValueError):
+        f("cbf-avlon")
+
+
+def test_product_path_refuses_cpu():
+    import torch
+    from marl_mass_amd import VecMergeEnv
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        VecMergeEnv(4, 4)

@@ -1,0 +1,137 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the reference's golden tapes and vs the
+CPU oracle on seeded random rollouts.  Flags bit-exact, floats within 1e-5 (north_star)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_env
+from golden_util import episode_files, replay, FLOAT_TOL
+from marl_mass_amd import VecMergeEnv, _cabi as abi
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_env(E, N, **kw):
+    return VecMergeEnv(E, N, device="cuda:0", **kw)
+
+
+@pytest.mark.parametrize("path", episode_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_golden_tape(path):
+    err = replay(_gpu_env, path)
+    print(os.path.basename(path), json.dumps({k: float("%.3g" % v) for k, v in err.items()}))
+
+
+CASES = [
+    # (env_id, safety, N, E, steps, eta, tau)  -- BASELINE configs c2..c4 at oracle-friendly sizes
+    ("merge-multi-agent-v0", "none", 4, 512, 40, 0.0, 1.2),
+    ("merge-multi-agent-v1", "none", 4, 256, 40, 0.0, 1.2),
+    ("merge-multi-agent-v1", "cbf-avs_cint", 4, 512, 100, 0.03125, 0.5),
+    ("merge-multi-agent-v1", "cbf-cav", 8, 512, 100, 0.03125, 0.5),
+    ("merge-multi-agent-v1", "cbf-cav", 5, 128, 60, 0.03125, 0.5),   # ragged group (N < G)
+    ("merge-multi-agent-v1", "cbf-cav", 11, 128, 60, 0.03125, 0.5),  # G = 16
+    ("merge-multi-agent-v1", "cbf-avs_cint", 2, 128, 60, 0.5, 1.2),
+]
+
+
+@pytest.mark.parametrize("env_id,safety,N,E,steps,eta,tau", CASES)
+def test_random_rollout_vs_oracle(env_id, safety, N, E, steps, eta, tau):
+    """Same seeds, same action tape, auto-reset on: every output of every step must agree."""
+    kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau}, cbf_eta=eta, cbf_tau=tau,
+              obs_f64=True, seed=1000, auto_reset=True)
+    gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
+    og, ag = gpu.reset()
+    oc, ac = cpu.reset()
+    assert torch.equal(gpu.u8.cpu(), cpu.u8)
+    assert torch.equal(gpu.f64.cpu()[:5], cpu.f64[:5]), "device reset must be bit-identical (integer RNG + exact fp)"
+    assert float((og.cpu() - oc).abs().max()) <= 1e-12
+    g = torch.Generator().manual_seed(123)
+    p = torch.tensor([0.1, 0.6, 0.1, 0.1, 0.1])
+    worst = 0.0
+    for t in range(steps):
+        a = torch.multinomial(p, E * N, True, generator=g).view(E, N).int()
+        og, rg, dg, ig = gpu.step(a.cuda())
+        oc, rc, dc, ic = cpu.step(a)
+        for k in ("done", "agents_dones", "crashed", "action_mask"):
+            assert torch.equal(ig[k].cpu(), ic[k]), (t, k)
+        assert torch.equal(gpu.u8.cpu(), cpu.u8), (t, "discrete state")
+        assert torch.equal(gpu.env_i32.cpu(), cpu.env_i32), (t, "episode counters")
+        errs = {"obs": (og.cpu() - oc).abs().max(), "state": (gpu.f64.cpu() - cpu.f64).nan_to_num().abs().max()}
+        for k in ("reward", "agents_rewards", "regional_rewards", "average_speed", "traffic_speed", "min_headway"):
+            errs[k] = (ig[k].cpu() - ic[k]).abs().max()
+        mp_g, mp_c = ig["merge_percent"].cpu(), ic["merge_percent"]
+        assert torch.equal(torch.isnan(mp_g), torch.isnan(mp_c))
+        errs["merge"] = (mp_g - mp_c).nan_to_num().abs().max()
+        m = max(float(v) for v in errs.values())
+        worst = max(worst, m)
+        assert m <= FLOAT_TOL, (t, {k: float(v) for k, v in errs.items()})
+    print("worst abs err %.3g over %d steps x %d envs" % (worst, steps, E))
+
+
+def test_float32_obs_matches_float64():
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
+              cbf_eta=0.03125, cbf_tau=0.5, seed=7)
+    e32, e64 = _gpu_env(256, 8, **kw), _gpu_env(256, 8, obs_f64=True, **kw)
+    o32, _ = e32.reset()
+    o64, _ = e64.reset()
+    assert o32.dtype == torch.float32 and torch.equal(o32, o64.float())
+    a = torch.ones(256, 8, dtype=torch.int32, device="cuda:0")
+    for _ in range(5):
+        o32 = e32.step(a)[0]
+        o64 = e64.step(a)[0]
+    assert torch.equal(o32, o64.float())
+
+
+def test_shield_qp_entry_matches_golden(golden_dir):
+    """mm_shield_qp on every (G, h) the reference assembled vs the exact-KKT u_bar in the tape."""
+    z = np.load(os.path.join(golden_dir, "ep_v1_mass_N8_lc_s75.npz"))
+    env = _gpu_env(1, 2)
+    u, st = env.shield_qp(z["qp_G"], np.nan_to_num(z["qp_h"]), z["qp_rows"])
+    assert bool(st.all())
+    np.testing.assert_allclose(u.cpu().numpy()[:, 0], z["qp_x"][:, 0], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(u.cpu().numpy()[:, 2], z["qp_x"][:, 2], rtol=0, atol=1e-9)
+
+
+def test_metrics_accumulator():
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "none"}, seed=3, auto_reset=True)
+    env = _gpu_env(1024, 4, **kw)
+    m = env.enable_metrics()
+    env.reset()
+    a = torch.full((1024, 4), 3, dtype=torch.int32, device="cuda:0")
+    tot_r, tot_done, mn = 0.0, 0, float("inf")
+    for _ in range(30):
+        _, r, d, info = env.step(a)
+        tot_r += float(r.sum())
+        tot_done += int(d.sum())
+        mn = min(mn, float(info["min_headway"].min()))
+    mm = m.cpu()
+    assert abs(float(mm[0]) - tot_r) <= 1e-6 * max(1.0, abs(tot_r))
+    assert int(mm[6]) == tot_done and int(mm[4]) == 30 * 1024
+    assert float(mm[7]) == mn
+
+
+def test_full_size_properties():
+    """BASELINE c4/c5-sized batch (65536 envs x 8, MASS): size-independent invariants.
+    With the shield on and eta=0.03125, tau=0.5 the reference never crashes under the random tape
+    (SURVEY App. B), and sharding the batch must not change any env."""
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
+              cbf_eta=0.03125, cbf_tau=0.5, seed=1000)
+    E, N = 65536, 8
+    env = _gpu_env(E, N, **kw)
+    half = VecMergeEnv(E // 2, N, device="cuda:0", first_env=E // 2, **kw)
+    env.reset()
+    half.reset()
+    assert torch.equal(env.f64[:, E // 2:], half.f64), "RNG streams are keyed by global env id"
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    p = torch.tensor([0.1, 0.6, 0.1, 0.1, 0.1], device="cuda:0")
+    for t in range(25):
+        a = torch.multinomial(p, E * N, True, generator=g).view(E, N).int()
+        obs, r, d, info = env.step(a)
+        half.step(a[E // 2:].contiguous())
+        assert not bool(info["crashed"].any()), "MASS-shielded env crashed at step %d" % t
+        assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(r).all())
+    assert torch.equal(env.f64[:, E // 2:].nan_to_num(), half.f64.nan_to_num()) and torch.equal(env.u8[:, E // 2:], half.u8)
+    xs = env.f64[abi.F["X"]]
+    assert bool((xs > 0).all()) and bool((env.f64[abi.F["SPEED"]] >= 0).all())
