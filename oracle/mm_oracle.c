@@ -1189,3 +1189,11 @@ void orc_batch_rect(int32_t n, const double *rect /*[n][6]*/, uint8_t *hit, uint
     hit_obstacle[k] = (uint8_t)rotated_rectangles_intersect(r[0], r[1], 4.5, 1.8, r[2], r[3], r[4], 1.8, 1.8, 0.0);
   }
 }
+
+/* thread control for the cpu_baseline leg of bench.py (OpenMP over envs) */
+#ifdef _OPENMP
+#include <omp.h>
+int32_t orc_set_threads(int32_t n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int32_t orc_set_threads(int32_t n) { (void)n; return 1; }
+#endif

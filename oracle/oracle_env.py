@@ -56,6 +56,7 @@ def library():
         lib.orc_wrap_to_pi.restype = d
         lib.orc_rect_intersect.argtypes = [d] * 10
         vp = C.c_void_p
+        lib.orc_set_threads.argtypes = [i32]
         lib.orc_batch_pose.argtypes = [i32] + [vp] * 11
         lib.orc_batch_steering.argtypes = [i32] + [vp] * 7
         lib.orc_batch_rect.argtypes = [i32] + [vp] * 3
