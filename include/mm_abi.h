@@ -167,6 +167,9 @@ enum {
   MM_T_QP_A,                      /* G[0][0] = g_e.vx * dt                      */
   MM_T_QP_H0, MM_T_QP_H1, MM_T_QP_H2, MM_T_QP_H3, /* h vector (H3 NaN if 3 rows) */
   MM_T_QP_D,                      /* u_bar[0] returned by the QP                */
+  MM_T_LC_MARGIN,                 /* min of the four is_lc_allowed quantities (cbf.py:335-339):
+                                     lane change allowed <=> margin >= 0.  Structurally ~0 (sign =
+                                     rounding noise) when the adjacent CBF row is the active one */
   MM_T_COUNT
 };
 
@@ -241,6 +244,13 @@ int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec,
 int32_t mm_set_metrics_buffer(MMHandle h, double *metrics);
 
 const char *mm_last_error(MMHandle h);
+
+/*
+ * Diagnostics: evaluate one elementary function of include/mm_math.h element-wise
+ * (fn: 0 sin, 1 cos, 2 tan, 3 atan, 4 asin, 5 exp, 6 log, 7 sqrt, 8 x/y with y = x2[i]).
+ * x, x2 (may be NULL unless fn == 8), y: DEV double[n].  Used to prove CPU/GPU bit equality.
+ */
+int32_t mm_math_eval(int32_t fn, int32_t n, const double *x, const double *x2, double *y, MMStream stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,203 @@
+/*
+ * mm_math.h -- bit-reproducible fp64 elementary functions for the merge env.
+ *
+ * Why: the shield's lane-change test (cbf.py:324-339) evaluates a quantity that is structurally
+ * ~0 whenever the adjacent-vehicle CBF row is the active QP constraint, so its sign is decided by
+ * rounding noise.  For the HIP path and its CPU checker to agree on such decisions they must
+ * agree on every bit, which needs identical sin/cos/tan/atan/asin/exp/log.  These versions use
+ * only IEEE-exact primitives (+ - * / sqrt fma ldexp frexp rint) in a fixed order, so gcc on
+ * x86-64 (-mfma, -ffp-contract=off) and hipcc on gfx950 (-ffp-contract=off) give identical
+ * bits.  Accuracy ~1 ulp (2 ulp for tan/asin); range-reduced for the arguments this path
+ * produces (angles of a few radians, exp of [-1e3, 0], log of positive normal numbers).
+ *
+ * Constants are derived by tools/gen_math_consts.py (80-digit arithmetic): split pi/2 and ln 2,
+ * atan(j/4), and plain Taylor coefficients (the reduced intervals are small enough that Taylor
+ * truncation stays below 2^-56).
+ *
+ * The includer defines MMM_FN (e.g. `static inline` or `__device__ __forceinline__`).
+ */
+#ifndef MM_MATH_H
+#define MM_MATH_H
+
+#ifndef MMM_FN
+#define MMM_FN static inline
+#endif
+
+#define MMM_PIO2_1 0x1.921fb54400000p+0 /* 1.5707963267341256 */
+#define MMM_PIO2_1T 0x1.0b4611a626331p-34 /* 6.0771005065061922e-11 */
+#define MMM_PIO2_HI 0x1.921fb54442d18p+0 /* 1.5707963267948966 */
+#define MMM_PIO2_LO 0x1.1a62633145c07p-54 /* 6.123233995736766e-17 */
+#define MMM_TWO_OVER_PI 0x1.45f306dc9c883p-1 /* 0.63661977236758138 */
+#define MMM_LN2_HI 0x1.62e42ff000000p-1 /* 0.69314718060195446 */
+#define MMM_LN2_LO -0x1.718432a1b0e26p-35 /* -4.2009150726810846e-11 */
+#define MMM_INV_LN2 0x1.71547652b82fep+0 /* 1.4426950408889634 */
+#define MMM_SQRT_HALF 0x1.6a09e667f3bcdp-1 /* 0.70710678118654757 */
+#define MMM_ATAN_HI_1 0x1.f5b75f92c80ddp-3 /* 0.24497866312686414 */
+#define MMM_ATAN_LO_1 0x1.8ab6e3cf7afbdp-57 /* 1.0698755618734451e-17 */
+#define MMM_ATAN_HI_2 0x1.dac670561bb4fp-2 /* 0.46364760900080609 */
+#define MMM_ATAN_LO_2 0x1.a2b7f222f65e2p-56 /* 2.2698777452961687e-17 */
+#define MMM_ATAN_HI_3 0x1.4978fa3269ee1p-1 /* 0.64350110879328437 */
+#define MMM_ATAN_LO_3 0x1.2419a87f2a458p-56 /* 1.5834785051444286e-17 */
+#define MMM_ATAN_HI_4 0x1.921fb54442d18p-1 /* 0.78539816339744828 */
+#define MMM_ATAN_LO_4 0x1.1a62633145c07p-55 /* 3.061616997868383e-17 */
+#define MMM_S1 -0x1.5555555555555p-3 /* -0.16666666666666666 */
+#define MMM_S2 0x1.1111111111111p-7 /* 0.0083333333333333332 */
+#define MMM_S3 -0x1.a01a01a01a01ap-13 /* -0.00019841269841269841 */
+#define MMM_S4 0x1.71de3a556c734p-19 /* 2.7557319223985893e-06 */
+#define MMM_S5 -0x1.ae64567f544e4p-26 /* -2.505210838544172e-08 */
+#define MMM_S6 0x1.6124613a86d09p-33 /* 1.6059043836821613e-10 */
+#define MMM_S7 -0x1.ae7f3e733b81fp-41 /* -7.6471637318198164e-13 */
+#define MMM_C2 0x1.5555555555555p-5 /* 0.041666666666666664 */
+#define MMM_C3 -0x1.6c16c16c16c17p-10 /* -0.0013888888888888889 */
+#define MMM_C4 0x1.a01a01a01a01ap-16 /* 2.4801587301587302e-05 */
+#define MMM_C5 -0x1.27e4fb7789f5cp-22 /* -2.7557319223985888e-07 */
+#define MMM_C6 0x1.1eed8eff8d898p-29 /* 2.08767569878681e-09 */
+#define MMM_C7 -0x1.93974a8c07c9dp-37 /* -1.1470745597729725e-11 */
+#define MMM_C8 0x1.ae7f3e733b81fp-45 /* 4.7794773323873853e-14 */
+#define MMM_A1 -0x1.5555555555555p-2 /* -0.33333333333333331 */
+#define MMM_A2 0x1.999999999999ap-3 /* 0.20000000000000001 */
+#define MMM_A3 -0x1.2492492492492p-3 /* -0.14285714285714285 */
+#define MMM_A4 0x1.c71c71c71c71cp-4 /* 0.1111111111111111 */
+#define MMM_A5 -0x1.745d1745d1746p-4 /* -0.090909090909090912 */
+#define MMM_A6 0x1.3b13b13b13b14p-4 /* 0.076923076923076927 */
+#define MMM_A7 -0x1.1111111111111p-4 /* -0.066666666666666666 */
+#define MMM_A8 0x1.e1e1e1e1e1e1ep-5 /* 0.058823529411764705 */
+#define MMM_A9 -0x1.af286bca1af28p-5 /* -0.052631578947368418 */
+#define MMM_A10 0x1.8618618618618p-5 /* 0.047619047619047616 */
+#define MMM_E2 0x1.0000000000000p-1 /* 0.5 */
+#define MMM_E3 0x1.5555555555555p-3 /* 0.16666666666666666 */
+#define MMM_E4 0x1.5555555555555p-5 /* 0.041666666666666664 */
+#define MMM_E5 0x1.1111111111111p-7 /* 0.0083333333333333332 */
+#define MMM_E6 0x1.6c16c16c16c17p-10 /* 0.0013888888888888889 */
+#define MMM_E7 0x1.a01a01a01a01ap-13 /* 0.00019841269841269841 */
+#define MMM_E8 0x1.a01a01a01a01ap-16 /* 2.4801587301587302e-05 */
+#define MMM_E9 0x1.71de3a556c734p-19 /* 2.7557319223985893e-06 */
+#define MMM_E10 0x1.27e4fb7789f5cp-22 /* 2.7557319223985888e-07 */
+#define MMM_E11 0x1.ae64567f544e4p-26 /* 2.505210838544172e-08 */
+#define MMM_E12 0x1.1eed8eff8d898p-29 /* 2.08767569878681e-09 */
+#define MMM_E13 0x1.6124613a86d09p-33 /* 1.6059043836821613e-10 */
+#define MMM_E14 0x1.93974a8c07c9dp-37 /* 1.1470745597729725e-11 */
+#define MMM_L1 0x1.5555555555555p-2 /* 0.33333333333333331 */
+#define MMM_L2 0x1.999999999999ap-3 /* 0.20000000000000001 */
+#define MMM_L3 0x1.2492492492492p-3 /* 0.14285714285714285 */
+#define MMM_L4 0x1.c71c71c71c71cp-4 /* 0.1111111111111111 */
+#define MMM_L5 0x1.745d1745d1746p-4 /* 0.090909090909090912 */
+#define MMM_L6 0x1.3b13b13b13b14p-4 /* 0.076923076923076927 */
+#define MMM_L7 0x1.1111111111111p-4 /* 0.066666666666666666 */
+#define MMM_L8 0x1.e1e1e1e1e1e1ep-5 /* 0.058823529411764705 */
+#define MMM_L9 0x1.af286bca1af28p-5 /* 0.052631578947368418 */
+#define MMM_L10 0x1.8618618618618p-5 /* 0.047619047619047616 */
+#define MMM_L11 0x1.642c8590b2164p-5 /* 0.043478260869565216 */
+
+/* sin / cos kernels on |r| <= pi/4 (Taylor to r^15 / r^16) */
+MMM_FN double mmm_ksin(double r) {
+  double z = r * r;
+  double p = MMM_S7;
+  p = fma(p, z, MMM_S6); p = fma(p, z, MMM_S5); p = fma(p, z, MMM_S4);
+  p = fma(p, z, MMM_S3); p = fma(p, z, MMM_S2); p = fma(p, z, MMM_S1);
+  return fma(r * z, p, r);
+}
+MMM_FN double mmm_kcos(double r) {
+  double z = r * r;
+  double q = MMM_C8;
+  q = fma(q, z, MMM_C7); q = fma(q, z, MMM_C6); q = fma(q, z, MMM_C5);
+  q = fma(q, z, MMM_C4); q = fma(q, z, MMM_C3); q = fma(q, z, MMM_C2);
+  return fma(z * z, q, fma(-0.5, z, 1.0));
+}
+/* Cody-Waite reduction by pi/2 (two-part constant: exact for |k| < 2^19) */
+MMM_FN double mmm_reduce(double x, int *quadrant) {
+  double k = rint(x * MMM_TWO_OVER_PI);
+  double r = fma(-k, MMM_PIO2_1, x);
+  r = fma(-k, MMM_PIO2_1T, r);
+  *quadrant = ((int)k) & 3;
+  return r;
+}
+MMM_FN double mmm_sin(double x) {
+  int q;
+  double r = mmm_reduce(x, &q);
+  double s = (q & 1) ? mmm_kcos(r) : mmm_ksin(r);
+  return (q & 2) ? -s : s;
+}
+MMM_FN double mmm_cos(double x) {
+  int q;
+  double r = mmm_reduce(x, &q);
+  double c = (q & 1) ? mmm_ksin(r) : mmm_kcos(r);
+  return ((q + 1) & 2) ? -c : c;
+}
+MMM_FN void mmm_sincos(double x, double *s, double *c) {
+  int q;
+  double r = mmm_reduce(x, &q);
+  double ks = mmm_ksin(r), kc = mmm_kcos(r);
+  double ss = (q & 1) ? kc : ks, cc = (q & 1) ? ks : kc;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
+/* tan for |x| < pi/2 (steering angles are clipped to pi/3) */
+MMM_FN double mmm_tan(double x) {
+  double s, c;
+  mmm_sincos(x, &s, &c);
+  return s / c;
+}
+/* atan on [0, 1]: nearest breakpoint c = j/4, t = (x - c) / (1 + x c), |t| <= 1/8, Taylor to t^21 */
+MMM_FN double mmm_atan01(double ax, double *lo_out) {
+  int j = (int)(4.0 * ax + 0.5);
+  double c = 0.25 * (double)j;
+  double t = (j == 0) ? ax : (ax - c) / fma(ax, c, 1.0);
+  double z = t * t;
+  double p = MMM_A10;
+  p = fma(p, z, MMM_A9); p = fma(p, z, MMM_A8); p = fma(p, z, MMM_A7); p = fma(p, z, MMM_A6);
+  p = fma(p, z, MMM_A5); p = fma(p, z, MMM_A4); p = fma(p, z, MMM_A3); p = fma(p, z, MMM_A2);
+  p = fma(p, z, MMM_A1);
+  double pt = fma(t * z, p, t);
+  double hi = j == 0 ? 0.0 : (j == 1 ? MMM_ATAN_HI_1 : (j == 2 ? MMM_ATAN_HI_2 : (j == 3 ? MMM_ATAN_HI_3 : MMM_ATAN_HI_4)));
+  double lo = j == 0 ? 0.0 : (j == 1 ? MMM_ATAN_LO_1 : (j == 2 ? MMM_ATAN_LO_2 : (j == 3 ? MMM_ATAN_LO_3 : MMM_ATAN_LO_4)));
+  *lo_out = lo;
+  return hi + (pt + lo);
+}
+MMM_FN double mmm_atan(double x) {
+  double ax = fabs(x), lo;
+  double r;
+  if (ax > 1.0) r = MMM_PIO2_HI - (mmm_atan01(1.0 / ax, &lo) - MMM_PIO2_LO);
+  else r = mmm_atan01(ax, &lo);
+  return x < 0 ? -r : r;
+}
+/* asin(x) = atan2(|x|, sqrt((1-|x|)(1+|x|))), |x| <= 1 */
+MMM_FN double mmm_asin(double x) {
+  double y = fabs(x), lo;
+  double w = sqrt((1.0 - y) * (1.0 + y));
+  double r;
+  if (y <= w) r = mmm_atan01(y / w, &lo);
+  else r = MMM_PIO2_HI - (mmm_atan01(w / y, &lo) - MMM_PIO2_LO);
+  return x < 0 ? -r : r;
+}
+/* exp: x = k ln2 + r, |r| <= ln2/2, Taylor to r^14, exact scaling */
+MMM_FN double mmm_exp(double x) {
+  if (x < -1000.0) return 0.0;
+  double k = rint(x * MMM_INV_LN2);
+  double r = fma(-k, MMM_LN2_HI, x);
+  r = fma(-k, MMM_LN2_LO, r);
+  double p = MMM_E14;
+  p = fma(p, r, MMM_E13); p = fma(p, r, MMM_E12); p = fma(p, r, MMM_E11); p = fma(p, r, MMM_E10);
+  p = fma(p, r, MMM_E9); p = fma(p, r, MMM_E8); p = fma(p, r, MMM_E7); p = fma(p, r, MMM_E6);
+  p = fma(p, r, MMM_E5); p = fma(p, r, MMM_E4); p = fma(p, r, MMM_E3); p = fma(p, r, MMM_E2);
+  p = fma(p, r * r, r) + 1.0; /* 1 + r + r^2 (1/2 + ...) */
+  return ldexp(p, (int)k);
+}
+/* log: x = m 2^e with m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1), atanh series to s^23 */
+MMM_FN double mmm_log(double x) {
+  int e;
+  double m = frexp(x, &e); /* m in [0.5, 1) */
+  if (m < MMM_SQRT_HALF) { m = m * 2.0; e -= 1; }
+  double f = m - 1.0;
+  double s = f / (2.0 + f);
+  double z = s * s;
+  double p = MMM_L11;
+  p = fma(p, z, MMM_L10); p = fma(p, z, MMM_L9); p = fma(p, z, MMM_L8); p = fma(p, z, MMM_L7);
+  p = fma(p, z, MMM_L6); p = fma(p, z, MMM_L5); p = fma(p, z, MMM_L4); p = fma(p, z, MMM_L3);
+  p = fma(p, z, MMM_L2); p = fma(p, z, MMM_L1);
+  double l = 2.0 * fma(s * z, p, s);
+  double de = (double)e;
+  return fma(de, MMM_LN2_HI, l + de * MMM_LN2_LO);
+}
+
+#endif /* MM_MATH_H */

@@ -19,7 +19,7 @@ B_PLANES = ["LANE", "TARGET_LANE", "SPEED_INDEX", "CRASHED", "HL_ACTION", "FLAGS
 E_PLANES = ["STEPS", "TIME", "N_MERGE", "EPISODE"]
 T_PLANES = ["X", "Y", "HEADING", "SPEED", "ACT_STEER", "ACT_ACC", "SAFE_STEER", "SAFE_ACC", "LANE",
             "TARGET_LANE", "CRASHED", "FLAGS", "QP_ROWS", "QP_A", "QP_H0", "QP_H1", "QP_H2", "QP_H3",
-            "QP_D"]
+            "QP_D", "LC_MARGIN"]
 F = {n: i for i, n in enumerate(F_PLANES)}
 B = {n: i for i, n in enumerate(B_PLANES)}
 EP = {n: i for i, n in enumerate(E_PLANES)}
@@ -123,7 +123,7 @@ class CLib(object):
 
     SYMBOLS = ["mm_abi_version", "mm_state_layout", "mm_create", "mm_destroy", "mm_set_config",
                "mm_reset", "mm_init_from_kinematics", "mm_observe", "mm_step", "mm_shield_qp",
-               "mm_set_metrics_buffer", "mm_last_error"]
+               "mm_set_metrics_buffer", "mm_last_error", "mm_math_eval"]
 
     def __init__(self, path):
         if not os.path.exists(path):
@@ -144,6 +144,7 @@ class CLib(object):
         lib.mm_shield_qp.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
         lib.mm_set_metrics_buffer.argtypes = [vp, vp]
         lib.mm_last_error.argtypes = [vp]
+        lib.mm_math_eval.argtypes = [i32, i32, vp, vp, vp, vp]
         lib.mm_last_error.restype = C.c_char_p
         for s in self.SYMBOLS:
             if s not in ("mm_abi_version", "mm_last_error"):

@@ -11,6 +11,8 @@
 #include "../../include/mm_abi.h"
 
 #define MM_DEV __device__ __forceinline__
+#define MMM_FN __device__ __forceinline__
+#include "../../include/mm_math.h"
 
 namespace mm {
 
@@ -55,10 +57,10 @@ MM_DEV double clipd(double x, double a, double b) { return fmin(fmax(x, a), b); 
 MM_DEV void lane_local(int l, double x, double y, double &s, double &r) {  // lane.py:164-168,208-210
   s = x - lane_sx(l);
   r = y - lane_sy(l);
-  if (l == MM_LANE_KB0) r = r - kSineAmp * sin(kSinePuls * s + kSinePhase);
+  if (l == MM_LANE_KB0) r = r - kSineAmp * mmm_sin(kSinePuls * s + kSinePhase);
 }
 MM_DEV double lane_heading_at(int l, double s) {  // lane.py:158-159, :204-206
-  return l == MM_LANE_KB0 ? 0.0 + atan(kSineAmp * kSinePuls * cos(kSinePuls * s + kSinePhase)) : 0.0;
+  return l == MM_LANE_KB0 ? 0.0 + mmm_atan(kSineAmp * kSinePuls * mmm_cos(kSinePuls * s + kSinePhase)) : 0.0;
 }
 MM_DEV double lane_distance(int l, double x, double y) {  // lane.py:97-100
   double s, r;
@@ -100,8 +102,8 @@ MM_DEV int closest_lane(double x, double y, double h) {
     // bounds it from below: skip the transcendental frame when kb0 cannot win (ties lose: last id)
     if (!((0.0 + tail) + head >= bd)) {
       double ph = kSinePuls * s + kSinePhase;
-      double r = (y - 7.25) - kSineAmp * sin(ph);
-      double lh = 0.0 + atan(kSineAmp * kSinePuls * cos(ph));
+      double r = (y - 7.25) - kSineAmp * mmm_sin(ph);
+      double lh = 0.0 + mmm_atan(kSineAmp * kSinePuls * mmm_cos(ph));
       double d = fabs(r) + tail + head + 1.0 * fabs(wrap_to_pi(h - lh));
       if (d < bd) { bd = d; best = MM_LANE_KB0; }
     }
@@ -131,10 +133,10 @@ MM_DEV double steering_control(double x, double y, double heading, double speed,
   double lfh = lane_heading_at(tl, lane_next);
   double lat_cmd = -KP_LATERAL * r;
   double nz = not_zero(speed);
-  double heading_command = asin(clipd(lat_cmd / nz, -1, 1));
+  double heading_command = mmm_asin(clipd(lat_cmd / nz, -1, 1));
   double heading_ref = lfh + clipd(heading_command, -kPi / 4, kPi / 4);
   double rate = KP_HEADING * wrap_to_pi(heading_ref - heading);
-  double steer = asin(clipd(kVehLength / 2 / nz * rate, -1, 1));
+  double steer = mmm_asin(clipd(kVehLength / 2 / nz * rate, -1, 1));
   return clipd(steer, -kPi / 3, kPi / 3);
 }
 
@@ -142,7 +144,7 @@ MM_DEV double steering_control(double x, double y, double heading, double speed,
 MM_DEV bool has_corner_inside(double c1x, double c1y, double l1, double w1, double a1, double c2x,
                               double c2y, double l2, double w2, double a2) {
   const double lx = l1 / 2, wy = w1 / 2;
-  double c = cos(a1), s = sin(a1), c2 = cos(a2), s2 = sin(a2);
+  double c = mmm_cos(a1), s = mmm_sin(a1), c2 = mmm_cos(a2), s2 = mmm_sin(a2);
   const double px[9] = {0, -lx, lx, 0, 0, -lx, -lx, lx, lx};
   const double py[9] = {0, 0, 0, -wy, wy, -wy, wy, -wy, wy};
   bool any = false;

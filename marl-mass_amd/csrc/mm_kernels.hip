@@ -156,11 +156,11 @@ MM_DEV void clip_actions(Veh &v) {
 
 // controller.py:257-267 get_corner("L"/"R") + lane.on_lane of those corners on `lane`
 MM_DEV void corner_flags(double x, double y, double h, int lane, bool &offL, bool &offR) {
-  double cx = x + (kCornerLen * cos(kCornerAlpha + h));
-  double cyL = y - (kCornerLen * sin(kCornerAlpha + h)) + 0.01;
-  double cyR = y - (kCornerLen * sin(-kCornerAlpha + h)) + 0.01;
+  double cx = x + (kCornerLen * mmm_cos(kCornerAlpha + h));
+  double cyL = y - (kCornerLen * mmm_sin(kCornerAlpha + h)) + 0.01;
+  double cyR = y - (kCornerLen * mmm_sin(-kCornerAlpha + h)) + 0.01;
   double s = cx - lane_sx(lane);
-  double off = (lane == MM_LANE_KB0) ? kSineAmp * sin(kSinePuls * s + kSinePhase) : 0.0;
+  double off = (lane == MM_LANE_KB0) ? kSineAmp * mmm_sin(kSinePuls * s + kSinePhase) : 0.0;
   bool lon = (-kVehLength <= s && s < lane_len(lane) + kVehLength);
   double rL = cyL - lane_sy(lane), rR = cyR - lane_sy(lane);
   if (lane == MM_LANE_KB0) { rL = rL - off; rR = rR - off; }
@@ -178,14 +178,14 @@ struct Cand {
 template <int KIND, bool SHIELDED>
 MM_DEV Cand predict(const Veh &v, double steer, double dt) {
   Cand c;
-  double beta = atan(1.0 / 2 * tan(steer));
-  double vx = v.v * cos(v.h + beta), vy = v.v * sin(v.h + beta);
+  double beta = mmm_atan(1.0 / 2 * mmm_tan(steer));
+  double vx = v.v * mmm_cos(v.h + beta), vy = v.v * mmm_sin(v.h + beta);
   c.x = v.x + vx * dt;
   c.y = v.y + vy * dt;
-  c.h = v.h + v.v * sin(beta) / (kVehLength / 2) * dt;
-  c.gvx = (KIND == MM_ENV_V1) ? cos(c.h + beta) : 0.0;
+  c.h = v.h + v.v * mmm_sin(beta) / (kVehLength / 2) * dt;
+  c.gvx = (KIND == MM_ENV_V1) ? mmm_cos(c.h + beta) : 0.0;
   c.lane = closest_lane(c.x, c.y, c.h);  // on_state_update kinematics.py:154-159
-  c.cpsi = (KIND == MM_ENV_V1) ? cos(c.h) : 0.0;
+  c.cpsi = (KIND == MM_ENV_V1) ? mmm_cos(c.h) : 0.0;
   c.offL = c.offR = false;
   if (SHIELDED) corner_flags(c.x, c.y, c.h, c.lane, c.offL, c.offR);
   return c;
@@ -199,7 +199,7 @@ MM_DEV int adj_lane(int l1, int nl1, int l2) {
 }
 
 struct QpTrace {
-  double rows, a, h0, h1, h2, h3, d;
+  double rows, a, h0, h1, h2, h3, d, margin;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -263,7 +263,7 @@ template <int G, int KIND, typename OBS_T>
 MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, bool valid, OBS_T *obs,
                     uint8_t *avail) {
   constexpr int F = (KIND == MM_ENV_V1) ? 6 : 5;
-  const double cps = cos(v.h), sps = sin(v.h);
+  const double cps = mmm_cos(v.h), sps = mmm_sin(v.h);
   const double vx = v.v * cps, vy = v.v * sps;  // Vehicle.velocity kinematics.py:215-217
   const double sx = lane_sx(v.lane);
   double key[G];
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
   steps += 1;  // abstract.py:457
 
   // derived per-vehicle registers the shield keeps current across sub-steps
-  double cpsi = (SHIELDED && v.present) ? cos(v.h) : 1.0;
+  double cpsi = (SHIELDED && v.present) ? mmm_cos(v.h) : 1.0;
   bool offL = false, offR = false;
   int nl_self = 0;
   if (SHIELDED && v.present) {
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
   for (int k = 0; k < c.nsub; k++) {
     const bool live = env_active && v.present;
     QpTrace qt = {0, __builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan(""),
-                  __builtin_nan(""), __builtin_nan("")};
+                  __builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
     if (live) {
       if (time % c.nsub == 0) mdp_act<KIND>(v, action);  // action_type.act abstract.py:516-519
       mdp_act<KIND>(v, -1);                              // road.act road.py:269-278
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
             ol_acc = shfl_d(v.safe_acc, s_ol); ol_g = shfl_d(v.gvx, s_ol);
             oa_acc = shfl_d(v.safe_acc, s_oa); oa_g = shfl_d(v.gvx, s_oa);
           }
-          // s_oar = veh.to_dict(): current x and vx = speed*cos(heading)
+          // s_oar = veh.to_dict(): current x and vx = speed*mmm_cos(heading)
           const double oar_x = shfl_d(v.x, s_oar), oar_vx = shfl_d(v.v * cpsi, s_oar);
           bool constrain_adj = MASS && has_oa && (f_oa & 1u);
           if (!has_ol) { ol_acc = 0; ol_g = 0; }  // defaults a_ol / gp["ol"] (:93-95)
@@ -579,6 +579,8 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
             v.flags = fl;
             qt.rows = (MASS && constrain_adj) ? 4 : 3; qt.a = g0; qt.h0 = h0; qt.h1 = h1; qt.h2 = h2;
             qt.h3 = h3; qt.d = d;
+            qt.margin = fmin(fmin(hls_lona, hlds_lona + (eta - 1) * hls_lona),
+                             fmin(hls_lonr, hlds_lonr + (eta - 1) * hls_lonr));
             // commit Vehicle.step now: followers must see this vehicle's post-step state
             const Cand &cc = use_B ? cB : cA;
             double nv = v.v + new_acc * dt;
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
       t[MM_T_LANE * A] = v.lane; t[MM_T_TARGET_LANE * A] = v.tlane; t[MM_T_CRASHED * A] = v.crashed;
       t[MM_T_FLAGS * A] = v.flags; t[MM_T_QP_ROWS * A] = qt.rows; t[MM_T_QP_A * A] = qt.a;
       t[MM_T_QP_H0 * A] = qt.h0; t[MM_T_QP_H1 * A] = qt.h1; t[MM_T_QP_H2 * A] = qt.h2;
-      t[MM_T_QP_H3 * A] = qt.h3; t[MM_T_QP_D * A] = qt.d;
+      t[MM_T_QP_H3 * A] = qt.h3; t[MM_T_QP_D * A] = qt.d; t[MM_T_LC_MARGIN * A] = qt.margin;
     }
     // _is_terminal (merge_env_v1.py:168-172) breaks the sub-step loop (abstract.py:530)
     const bool term = group_ballot<G>(v.present && (v.crashed || v.x < 0), gb) != 0 || steps >= c.T;
@@ -730,8 +732,8 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
   if (v.present) {
     double scaled = 0 + (v.v - c.rs_lo) * (1 - 0) / (c.rs_hi - c.rs_lo);
     double merging = 0;
-    if (v.lane == MM_LANE_BC1) { double t = v.x - 420; merging = -exp(-(t * t) / (10 * 100)); }
-    double hc = v.v > 0 ? log(hd / (c.headway_time * v.v)) : 0;
+    if (v.lane == MM_LANE_BC1) { double t = v.x - 420; merging = -mmm_exp(-(t * t) / (10 * 100)); }
+    double hc = v.v > 0 ? mmm_log(hd / (c.headway_time * v.v)) : 0;
     local = c.collision_reward * (-1 * v.crashed) + (c.high_speed_reward * clipd(scaled, 0, 1)) +
             c.merging_lane_cost * merging + c.headway_cost * (hc < 0 ? hc : 0);
   }
@@ -765,7 +767,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
     double h2d = hd;
     if (fabs(kObstY - v.y) <= 2 && kObstX > v.x) { double dd = kObstX - v.x; if (dd < h2d) h2d = dd; }
     h2d = h2d - kVehLength;
-    double vx = v.v * cos(v.h);
+    double vx = v.v * mmm_cos(v.h);
     th = h2d / (vx > 1 ? vx : 1);
   }
   const double min_headway = group_min_d<G>(th);
@@ -1084,4 +1086,30 @@ extern "C" int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const do
   hipError_t rc = hipGetLastError();
   if (rc != hipSuccess) return h ? hip_fail(h, rc, "qp launch") : MM_ERR_DEVICE;
   return MM_OK;
+}
+
+// diagnostics: element-wise mm_math evaluation (CPU/GPU bit-equality tests)
+__global__ void math_kernel(int fn, int n, const double *__restrict__ x, const double *__restrict__ x2,
+                            double *__restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = x[i], r;
+  switch (fn) {
+    case 0: r = mmm_sin(v); break;
+    case 1: r = mmm_cos(v); break;
+    case 2: r = mmm_tan(v); break;
+    case 3: r = mmm_atan(v); break;
+    case 4: r = mmm_asin(v); break;
+    case 5: r = mmm_exp(v); break;
+    case 6: r = mmm_log(v); break;
+    case 7: r = sqrt(v); break;
+    default: r = v / x2[i]; break;
+  }
+  y[i] = r;
+}
+extern "C" int32_t mm_math_eval(int32_t fn, int32_t n, const double *x, const double *x2, double *y,
+                                MMStream stream) {
+  if (fn < 0 || fn > 8 || n <= 0) return MM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(math_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, fn, n, x, x2, y);
+  return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_DEVICE;
 }

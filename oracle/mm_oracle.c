@@ -27,6 +27,29 @@
 
 #define PI 3.141592653589793 /* np.pi */
 
+/*
+ * Elementary-function mode.  0 (default): the platform libm, i.e. the reference's own arithmetic
+ * (CPython/numpy call the same libm) -- this is the mode pinned bit-tight to the golden tapes.
+ * 1: the bit-reproducible functions of include/mm_math.h, identical to what the HIP kernels
+ * evaluate, so that HIP-vs-oracle comparisons can demand equality of every bit (decisions such as
+ * the LC veto are rounding-noise knife-edges, see mm_math.h).  Mode 1 is itself checked against
+ * the golden tapes (<= 1e-9, same flags) in tests/test_oracle_golden.py.
+ */
+#define MMM_FN static inline
+#include "../include/mm_math.h"
+static double pow2_libm(double x) { return pow(x, 2); }
+static double pow2_mul(double x) { return x * x; }
+static double (*m_sin)(double) = sin, (*m_cos)(double) = cos, (*m_tan)(double) = tan;
+static double (*m_atan)(double) = atan, (*m_asin)(double) = asin, (*m_exp)(double) = exp;
+static double (*m_log)(double) = log, (*m_sq)(double) = pow2_libm;
+static int g_math_mode = 0;
+int32_t orc_set_math(int32_t mode) {
+  g_math_mode = mode;
+  if (mode == 0) { m_sin = sin; m_cos = cos; m_tan = tan; m_atan = atan; m_asin = asin; m_exp = exp; m_log = log; m_sq = pow2_libm; }
+  else { m_sin = mmm_sin; m_cos = mmm_cos; m_tan = mmm_tan; m_atan = mmm_atan; m_asin = mmm_asin; m_exp = mmm_exp; m_log = mmm_log; m_sq = pow2_mul; }
+  return g_math_mode;
+}
+
 /* ------------------------------------------------------------------ constants */
 #define VEH_LENGTH 5.0           /* kinematics.py:27 */
 #define VEH_WIDTH 2.0            /* kinematics.py:29 */
@@ -64,7 +87,7 @@ typedef struct {
   int lane, target_lane, speed_index, crashed, hl_action, flags, hist_len, kind;
   double local_reward, regional_reward;
   /* trace of the last shield call */
-  double qp_rows, qp_a, qp_h[4], qp_d;
+  double qp_rows, qp_a, qp_h[4], qp_d, lc_margin;
 } Veh;
 
 typedef struct {
@@ -109,7 +132,7 @@ static double clipd(double x, double a, double b) { return fmin(fmax(x, a), b); 
 /* utils.py:55-70 point_in_rotated_rectangle; NOTE rotates by +angle (upstream quirk, kept) */
 static int point_in_rotated_rectangle(double px, double py, double cx, double cy, double length,
                                       double width, double angle) {
-  double c = cos(angle), s = sin(angle);
+  double c = m_cos(angle), s = m_sin(angle);
   double dx = px - cx, dy = py - cy;
   double ru0 = c * dx + (-s) * dy;
   double ru1 = s * dx + c * dy;
@@ -122,7 +145,7 @@ static int has_corner_inside(double c1x, double c1y, double l1, double w1, doubl
   double lx = l1 / 2, wy = w1 / 2;
   double pts[9][2] = {{0, 0},     {-lx, 0},  {lx, 0},    {0, -wy},  {0, wy},
                       {-lx, -wy}, {-lx, wy}, {lx, -wy}, {lx, wy}};
-  double c = cos(a1), s = sin(a1);
+  double c = m_cos(a1), s = m_sin(a1);
   for (int k = 0; k < 9; k++) {
     double rx = c * pts[k][0] + (-s) * pts[k][1];
     double ry = s * pts[k][0] + c * pts[k][1];
@@ -143,13 +166,13 @@ static int rotated_rectangles_intersect(double c1x, double c1y, double l1, doubl
 static void lane_local(int lane, double x, double y, double *s, double *r) {
   double lon = x - LANE_SX[lane];
   double lat = y - LANE_SY[lane];
-  if (lane == MM_LANE_KB0) lat = lat - SINE_AMP * sin(SINE_PULS * lon + SINE_PHASE);
+  if (lane == MM_LANE_KB0) lat = lat - SINE_AMP * m_sin(SINE_PULS * lon + SINE_PHASE);
   *s = lon;
   *r = lat;
 }
 /* lane.py:158-159, :204-206 */
 static double lane_heading_at(int lane, double s) {
-  if (lane == MM_LANE_KB0) return 0.0 + atan(SINE_AMP * SINE_PULS * cos(SINE_PULS * s + SINE_PHASE));
+  if (lane == MM_LANE_KB0) return 0.0 + m_atan(SINE_AMP * SINE_PULS * m_cos(SINE_PULS * s + SINE_PHASE));
   return 0.0;
 }
 /* lane.py:97-100 distance */
@@ -241,11 +264,11 @@ static double steering_control(const Veh *v, int target_lane) {
   double lane_next = s + v->speed * PURSUIT_TAU;
   double lane_future_heading = lane_heading_at(target_lane, lane_next);
   double lateral_speed_command = -KP_LATERAL * r;
-  double heading_command = asin(clipd(lateral_speed_command / not_zero(v->speed), -1, 1));
+  double heading_command = m_asin(clipd(lateral_speed_command / not_zero(v->speed), -1, 1));
   double heading_ref = lane_future_heading + clipd(heading_command, -PI / 4, PI / 4);
   double heading_rate_command = KP_HEADING * wrap_to_pi(heading_ref - v->heading);
   double steering_angle =
-      asin(clipd(VEH_LENGTH / 2 / not_zero(v->speed) * heading_rate_command, -1, 1));
+      m_asin(clipd(VEH_LENGTH / 2 / not_zero(v->speed) * heading_rate_command, -1, 1));
   return clipd(steering_angle, -MAX_STEER, MAX_STEER);
 }
 /* controller.py:189-197 */
@@ -281,10 +304,10 @@ static void mdp_act(Veh *v, int action, int is_lc) {
 /* controller.py:257-267 get_corner; dir 0 = "L", 1 = "R" */
 static void get_corner(const Veh *v, int dir, double *cx, double *cy) {
   const double CORNER_LEN = sqrt((VEH_WIDTH / 2) * (VEH_WIDTH / 2) + (VEH_LENGTH / 2) * (VEH_LENGTH / 2)) + 0.0075;
-  const double CORNER_ALPHA = atan(VEH_WIDTH / VEH_LENGTH);
-  *cx = v->x + (CORNER_LEN * cos(CORNER_ALPHA + v->heading));
-  if (dir == 0) *cy = v->y - (CORNER_LEN * sin(CORNER_ALPHA + v->heading)) + 0.01;
-  else *cy = v->y - (CORNER_LEN * sin(-CORNER_ALPHA + v->heading)) + 0.01;
+  const double CORNER_ALPHA = m_atan(VEH_WIDTH / VEH_LENGTH);
+  *cx = v->x + (CORNER_LEN * m_cos(CORNER_ALPHA + v->heading));
+  if (dir == 0) *cy = v->y - (CORNER_LEN * m_sin(CORNER_ALPHA + v->heading)) + 0.01;
+  else *cy = v->y - (CORNER_LEN * m_sin(-CORNER_ALPHA + v->heading)) + 0.01;
 }
 
 /* ------------------------------------------------------------------ safety/decentral_layer.py */
@@ -326,8 +349,8 @@ static void simplified_control(const NState *s, double acc, double steer, double
   double speed = s->speed;
   double v = s->vx + acc * dt;
   v = v > 0 ? v : 0; /* max(0, v) */
-  double beta = atan(0.5 * tan(steer));
-  *dpsi_out = (speed / vl * sin(beta)) + s->heading;
+  double beta = m_atan(0.5 * m_tan(steer));
+  *dpsi_out = (speed / vl * m_sin(beta)) + s->heading;
   *v_out = v;
 }
 
@@ -371,7 +394,7 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
   double v_max = veh->speed + LC_MAX_ACC * dt;
 
   /* s_e = vehicle.to_dict() (+ speed), vx floored at 1 (:307-309) */
-  NState s_e = {1, veh->x, veh->heading, veh->speed * cos(veh->heading), veh->speed};
+  NState s_e = {1, veh->x, veh->heading, veh->speed * m_cos(veh->heading), veh->speed};
   s_e.vx = s_e.vx > 1 ? s_e.vx : 1;
   double sf_ol[2] = {s_e.x + PERCEPTION_DIST + 1, 0.0};
   double sf_oa[2] = {s_e.x + PERCEPTION_DIST + 1, 0.0};
@@ -394,7 +417,7 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
       if (!s_oar.present && ld < 0) {
         s_oar.present = 1; /* veh.to_dict(): current state */
         s_oar.x = o->x; s_oar.heading = o->heading;
-        s_oar.vx = o->speed * cos(o->heading); s_oar.speed = o->speed;
+        s_oar.vx = o->speed * m_cos(o->heading); s_oar.speed = o->speed;
       } else if (!s_oa.present && ld >= 0) {
         s_oa.present = 1; /* veh.state_hist[-2] */
         s_oa.x = o->h2[0]; s_oa.heading = o->h2[1]; s_oa.vx = o->h2[2]; s_oa.speed = o->h2[3];
@@ -417,13 +440,13 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
   if (!(veh->x > OBST_X)) {
     if ((!s_ol.present || OBST_X <= s_ol.x) && fabs(OBST_Y - veh->y) <= 2) {
       s_ol.present = 1; s_ol.x = OBST_X; s_ol.heading = 0; s_ol.vx = 0.0;
-      s_ol.speed = 0.0 / cos(0.0); /* "cos_h" branch of simplified_control */
+      s_ol.speed = 0.0 / m_cos(0.0); /* "cos_h" branch of simplified_control */
       if (mass) { a_ol_acc = 0; a_ol_steer = 0; gp_ol = 0; }
     }
     double ady = fabs(OBST_Y - veh->y);
     if ((!s_oa.present || OBST_X <= s_oa.x) && (2 < ady && ady <= 4)) {
       s_oa.present = 1; s_oa.x = OBST_X; s_oa.heading = 0; s_oa.vx = 0.0;
-      s_oa.speed = 0.0 / cos(0.0);
+      s_oa.speed = 0.0 / m_cos(0.0);
       if (mass) { a_oa_acc = 0; a_oa_steer = 0; gp_oa = 0; constrain_adj = 0; }
     }
   }
@@ -502,6 +525,8 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
   double hlds_lonr = px_lonr + (g[0] * um[0] + (-g[6]) * um[6]) + q_lonr;
   int lc_allowed = ((hls_lona >= 0) && (hlds_lona + (eta - 1) * hls_lona) >= 0) &&
                    ((hls_lonr >= 0) && (hlds_lonr + (eta - 1) * hls_lonr) >= 0);
+  veh->lc_margin = fmin(fmin(hls_lona, hlds_lona + (eta - 1) * hls_lona),
+                        fmin(hls_lonr, hlds_lonr + (eta - 1) * hls_lonr));
   if (!mass) {
     if (!lc_allowed) { /* :501-506 */
       veh->target_lane = veh->lane;
@@ -549,24 +574,24 @@ static int vehicle_step(const MMConfig *cfg, Env *e, int i, double dt) {
   int rc = 0;
   clip_actions(v, is_lc);
   double steer = v->act_steer, acc = v->act_acc;
-  v->qp_rows = 0; v->qp_a = NAN; v->qp_d = NAN;
+  v->qp_rows = 0; v->qp_a = NAN; v->qp_d = NAN; v->lc_margin = NAN;
   v->qp_h[0] = v->qp_h[1] = v->qp_h[2] = v->qp_h[3] = NAN;
   if (is_lc && cfg->shield != MM_SHIELD_NONE && v->hist_len >= 2) /* gate :232-239 */
     rc = safety_layer(cfg, e, i, dt, &acc, &steer);
   if (is_lc) { v->safe_steer = steer; v->safe_acc = acc; }
-  double beta = atan(1.0 / 2 * tan(steer));
-  double vx = v->speed * cos(v->heading + beta);
-  double vy = v->speed * sin(v->heading + beta);
+  double beta = m_atan(1.0 / 2 * m_tan(steer));
+  double vx = v->speed * m_cos(v->heading + beta);
+  double vy = v->speed * m_sin(v->heading + beta);
   v->x += vx * dt;
   v->y += vy * dt;
-  v->heading += v->speed * sin(beta) / (VEH_LENGTH / 2) * dt;
+  v->heading += v->speed * m_sin(beta) / (VEH_LENGTH / 2) * dt;
   v->speed += acc * dt;
   v->speed = v->speed > 0 ? v->speed : 0; /* max(0, speed) */
-  if (is_lc) v->g_vx = cos(v->heading + beta);
+  if (is_lc) v->g_vx = m_cos(v->heading + beta);
   v->lane = closest_lane(v->x, v->y, v->heading); /* on_state_update kinematics.py:154-159 */
   if (is_lc) { /* log_step: state_hist.append(to_dict()) safe_controller.py:187-201 */
     memcpy(v->h2, v->h1, sizeof v->h1);
-    v->h1[0] = v->x; v->h1[1] = v->heading; v->h1[2] = v->speed * cos(v->heading);
+    v->h1[0] = v->x; v->h1[1] = v->heading; v->h1[2] = v->speed * m_cos(v->heading);
     v->h1[3] = v->speed;
     if (v->hist_len < 2) v->hist_len++;
   }
@@ -645,7 +670,7 @@ static int simulate(const MMConfig *cfg, Env *e, const int32_t *actions, double 
         t[MM_T_QP_ROWS * A] = v->qp_rows; t[MM_T_QP_A * A] = v->qp_a;
         t[MM_T_QP_H0 * A] = v->qp_h[0]; t[MM_T_QP_H1 * A] = v->qp_h[1];
         t[MM_T_QP_H2 * A] = v->qp_h[2]; t[MM_T_QP_H3 * A] = v->qp_h[3];
-        t[MM_T_QP_D * A] = v->qp_d;
+        t[MM_T_QP_D * A] = v->qp_d; t[MM_T_LC_MARGIN * A] = v->lc_margin;
       }
     }
     if (is_terminal(cfg, e)) break;
@@ -660,7 +685,7 @@ static void observe_agent(const MMConfig *cfg, const Env *e, int i, double *out)
   const int F = cfg->env_kind == MM_ENV_V1 ? 6 : 5;
   const Veh *me = &e->v[i];
   for (int k = 0; k < 5 * F; k++) out[k] = 0.0;
-  double evx = me->speed * cos(me->heading), evy = me->speed * sin(me->heading);
+  double evx = me->speed * m_cos(me->heading), evy = me->speed * m_sin(me->heading);
   double rows[5][6];
   int nrows = 1;
   rows[0][0] = 1; rows[0][1] = me->x; rows[0][2] = me->y; rows[0][3] = evx; rows[0][4] = evy;
@@ -669,7 +694,7 @@ static void observe_agent(const MMConfig *cfg, const Env *e, int i, double *out)
   int m = close_vehicles_to(e, i, PERCEPTION_DIST, 5 - 1, near);
   for (int k = 0; k < m; k++) {
     const Veh *o = &e->v[near[k]];
-    double ovx = o->speed * cos(o->heading), ovy = o->speed * sin(o->heading);
+    double ovx = o->speed * m_cos(o->heading), ovy = o->speed * m_sin(o->heading);
     rows[nrows][0] = 1; rows[nrows][1] = o->x - me->x; rows[nrows][2] = o->y - me->y;
     rows[nrows][3] = ovx - evx; rows[nrows][4] = ovy - evy; rows[nrows][5] = o->heading;
     nrows++;
@@ -727,9 +752,9 @@ static double agent_reward(const MMConfig *cfg, const Env *e, int i) {
   double scaled_speed = 0 + (v->speed - cfg->reward_speed_lo) * (1 - 0) /
                                 (cfg->reward_speed_hi - cfg->reward_speed_lo);
   double merging = 0;
-  if (v->lane == MM_LANE_BC1) merging = -exp(-pow(v->x - 420, 2) / (10 * 100));
+  if (v->lane == MM_LANE_BC1) merging = -m_exp(-m_sq(v->x - 420) / (10 * 100));
   double hd = compute_headway_distance(e, i);
-  double hc = v->speed > 0 ? log(hd / (cfg->headway_time * v->speed)) : 0;
+  double hc = v->speed > 0 ? m_log(hd / (cfg->headway_time * v->speed)) : 0;
   return cfg->collision_reward * (-1 * v->crashed) + (cfg->high_speed_reward * clipd(scaled_speed, 0, 1)) +
          cfg->merging_lane_cost * merging + cfg->headway_cost * (hc < 0 ? hc : 0);
 }
@@ -784,7 +809,7 @@ static double min_time_headway(const Env *e) {
       if (d < hd) hd = d;
     }
     hd = hd - VEH_LENGTH;
-    double vx = v->speed * cos(v->heading);
+    double vx = v->speed * m_cos(v->heading);
     double th = hd / (vx > 1 ? vx : 1);
     if (th < mh) mh = th;
   }
@@ -1126,6 +1151,25 @@ int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec,
     double s = a * d - hc;
     u_out[k * 3 + 0] = d; u_out[k * 3 + 1] = 0.0; u_out[k * 3 + 2] = s > 0 ? s : 0.0;
     if (status) status[k] = 1;
+  }
+  return MM_OK;
+}
+
+int32_t mm_math_eval(int32_t fn, int32_t n, const double *x, const double *x2, double *y, MMStream stream) {
+  (void)stream;
+  for (int i = 0; i < n; i++) {
+    switch (fn) {
+      case 0: y[i] = mmm_sin(x[i]); break;
+      case 1: y[i] = mmm_cos(x[i]); break;
+      case 2: y[i] = mmm_tan(x[i]); break;
+      case 3: y[i] = mmm_atan(x[i]); break;
+      case 4: y[i] = mmm_asin(x[i]); break;
+      case 5: y[i] = mmm_exp(x[i]); break;
+      case 6: y[i] = mmm_log(x[i]); break;
+      case 7: y[i] = sqrt(x[i]); break;
+      case 8: y[i] = x[i] / x2[i]; break;
+      default: return MM_ERR_INVALID_ARG;
+    }
   }
   return MM_OK;
 }

@@ -57,12 +57,18 @@ def library():
         lib.orc_rect_intersect.argtypes = [d] * 10
         vp = C.c_void_p
         lib.orc_set_threads.argtypes = [i32]
+        lib.orc_set_math.argtypes = [i32]
         lib.orc_batch_pose.argtypes = [i32] + [vp] * 11
         lib.orc_batch_steering.argtypes = [i32] + [vp] * 7
         lib.orc_batch_rect.argtypes = [i32] + [vp] * 3
         for n in ("orc_batch_pose", "orc_batch_steering", "orc_batch_rect"):
             getattr(lib, n).restype = None
     return _LIB
+
+
+def set_math_mode(mode):
+    """0: platform libm (= the reference's arithmetic, golden-pinned); 1: include/mm_math.h (= the HIP path's)."""
+    return library().lib.orc_set_math(int(mode))
 
 
 def OracleEnv(E, N, env_id="merge-multi-agent-v1", config=None, **kw):

@@ -40,8 +40,53 @@ def env_kwargs(meta):
                 obs_f64=True, trace=True)
 
 
-def replay(make_env, path, tol=FLOAT_TOL, check_qp=True):
-    """Run one golden tape on `make_env(E=1, N=n, **kw)`; assert parity; return max abs errors."""
+KNIFE_EDGE = 1e-9  # |LC margin| below this = the reference's own decision is rounding noise
+
+
+def _force_state(env, z, meta, t, s_at):
+    """Teacher forcing: load the reference's state at the start of step t (end of sub-step s_at-1)."""
+    F, B, EP = abi.F, abi.B, abi.EP
+    n = meta["n"]
+    gf, gi = z["sub_f"][s_at - 1], z["sub_i"][s_at - 1]
+    dev = env.device
+    put = lambda plane, v: plane.__setitem__(0, torch.as_tensor(np.asarray(v), device=dev).to(plane.dtype))  # noqa: E731
+    for name, col in (("X", "x"), ("Y", "y"), ("HEADING", "heading"), ("SPEED", "speed"),
+                      ("TARGET_SPEED", "target_speed"), ("SAFE_STEER", "safe_steer"), ("SAFE_ACC", "safe_acc"),
+                      ("G_VX", "g_vx")):
+        put(env.f64[F[name]], gf[:, SF[col]])
+    h1 = np.stack([gf[:, SF["x"]], gf[:, SF["heading"]], gf[:, SF["speed"]] * np.cos(gf[:, SF["heading"]]),
+                   gf[:, SF["speed"]]])
+    if s_at >= 2:
+        pf = z["sub_f"][s_at - 2]
+        h2 = np.stack([pf[:, SF["x"]], pf[:, SF["heading"]], pf[:, SF["speed"]] * np.cos(pf[:, SF["heading"]]),
+                       pf[:, SF["speed"]]])
+    else:
+        h2 = np.zeros((4, n))
+    for k, nm in enumerate(("X", "HEADING", "VX", "SPEED")):
+        put(env.f64[F["H1_" + nm]], h1[k])
+        put(env.f64[F["H2_" + nm]], h2[k])
+    put(env.u8[B["LANE"]], gi[:, SI["lane"]])
+    put(env.u8[B["TARGET_LANE"]], gi[:, SI["target_lane"]])
+    put(env.u8[B["SPEED_INDEX"]], gi[:, SI["speed_index"]])
+    put(env.u8[B["CRASHED"]], gi[:, SI["crashed"]])
+    put(env.u8[B["HL_ACTION"]], np.where(gi[:, SI["hl_action"]] < 0, 255, gi[:, SI["hl_action"]]))
+    put(env.u8[B["FLAGS"]], gi[:, SI["collaborate_adj"]] * abi.FLAG_COLLABORATE_ADJ
+        + gi[:, SI["is_lc_safe"]] * abi.FLAG_IS_LC_SAFE + gi[:, SI["is_collaborating"]] * abi.FLAG_IS_COLLABORATING)
+    put(env.u8[B["HIST_LEN"]], np.full(n, min(2, s_at)))
+    put(env.u8[B["KIND"]], np.ones(n))
+    env.env_i32[EP["STEPS"], 0] = t
+    env.env_i32[EP["TIME"], 0] = s_at
+    env.env_i32[EP["N_MERGE"], 0] = meta["n_merge"]
+
+
+def replay(make_env, path, tol=FLOAT_TOL, check_qp=True, teacher_forcing=True, max_knife_edges=0):
+    """Run one golden tape on `make_env(E=1, N=n, **kw)` and assert parity with the reference.
+
+    Every step starts from the reference's own state (teacher forcing), so each of the tape's
+    steps is an independent check.  Discrete state, flags and QP structure must match exactly and
+    floats within `tol` -- except where the lane-change test of the shield sits on its structural
+    knife-edge (|LC margin| < 1e-9, see include/mm_math.h): those steps are counted in
+    err["knife_edges"] (bounded by `max_knife_edges`) and skipped."""
     z, meta = load_episode(path)
     n = meta["n"]
     env = make_env(E=1, N=n, **env_kwargs(meta))
@@ -58,66 +103,91 @@ def replay(make_env, path, tol=FLOAT_TOL, check_qp=True):
     sub_f, sub_i, sub_count = z["sub_f"], z["sub_i"], z["sub_count"]
     qp_G, qp_h, qp_x, qp_rows = z["qp_G"], z["qp_h"], z["qp_x"], z["qp_rows"]
     is_v1 = meta["env_id"].endswith("v1")
+    shielded = meta["shield"] != "none"
     mx = dict(state=0.0, action=0.0, obs=0.0, reward=0.0, info=0.0, qp=0.0)
+    knife = 0
     s_at, q_at = 0, 0
+
+    class _KnifeEdge(Exception):
+        pass
+
+    def discrete(cond, tr, k, ctx):
+        """A discrete mismatch is legitimate only on the LC knife-edge of this or an earlier sub-step."""
+        if cond:
+            return
+        marg = tr[: k + 1, abi.T["LC_MARGIN"]]
+        if shielded and np.nanmin(np.abs(np.where(np.isnan(marg), np.inf, marg))) < KNIFE_EDGE:
+            raise _KnifeEdge()
+        raise AssertionError(ctx)
+
     for t in range(meta["steps"]):
+        nsub = int(sub_count[t])
+        nqp = int(z["qp_count"][t])
+        if teacher_forcing and t > 0:
+            _force_state(env, z, meta, t, s_at)
         a = torch.tensor(z["actions"][t][None], dtype=torch.int32, device=dev)
         obs, rew, done, out = env.step(a)
         tr = env.trace[:, :, 0].cpu().numpy()  # [3, T, n]
-        nsub = int(sub_count[t])
-        ran = ~np.isnan(tr[:, abi.T["X"], 0])
-        assert int(ran.sum()) == nsub, (t, ran, nsub)
-        for k in range(nsub):
-            gf, gi = sub_f[s_at + k], sub_i[s_at + k]
-            # discrete state: bit-exact
-            for name, col in (("LANE", "lane"), ("TARGET_LANE", "target_lane"), ("CRASHED", "crashed")):
-                got = tr[k, abi.T[name]].astype(np.int64)
-                assert np.array_equal(got, gi[:, SI[col]]), (path, t, k, name, got, gi[:, SI[col]])
-            for name, col in (("X", "x"), ("Y", "y"), ("HEADING", "heading"), ("SPEED", "speed")):
-                mx["state"] = max(mx["state"], float(np.abs(tr[k, abi.T[name]] - gf[:, SF[col]]).max()))
-            for name, col in (("ACT_STEER", "act_steer"), ("ACT_ACC", "act_acc")):
-                mx["action"] = max(mx["action"], float(np.abs(tr[k, abi.T[name]] - gf[:, SF[col]]).max()))
-            if is_v1:
-                for name, col in (("SAFE_STEER", "safe_steer"), ("SAFE_ACC", "safe_acc")):
-                    mx["action"] = max(mx["action"], float(np.abs(tr[k, abi.T[name]] - gf[:, SF[col]]).max()))
-                fl = tr[k, abi.T["FLAGS"]].astype(np.int64)
-                if meta["shield"] != "none":
+        step_mx = dict(mx)
+        try:
+            ran = ~np.isnan(tr[:, abi.T["X"], 0])
+            discrete(int(ran.sum()) == nsub, tr, 2, (path, t, "sub-step count", ran, nsub))
+            q_loc = q_at
+            for k in range(nsub):
+                gf, gi = sub_f[s_at + k], sub_i[s_at + k]
+                for name, col in (("LANE", "lane"), ("TARGET_LANE", "target_lane"), ("CRASHED", "crashed")):
+                    got = tr[k, abi.T[name]].astype(np.int64)
+                    discrete(np.array_equal(got, gi[:, SI[col]]), tr, k, (path, t, k, name, got, gi[:, SI[col]]))
+                if is_v1 and shielded:
+                    fl = tr[k, abi.T["FLAGS"]].astype(np.int64)
                     rows = tr[k, abi.T["QP_ROWS"]].astype(np.int64)
                     if rows.any():  # shield ran this sub-step: flags are defined
-                        assert np.array_equal((fl & abi.FLAG_IS_LC_SAFE) != 0, gi[:, SI["is_lc_safe"]] != 0), (path, t, k)
-                        assert np.array_equal((fl & abi.FLAG_IS_COLLABORATING) != 0, gi[:, SI["is_collaborating"]] != 0), (path, t, k)
-                        assert np.array_equal((fl & abi.FLAG_COLLABORATE_ADJ) != 0, gi[:, SI["collaborate_adj"]] != 0), (path, t, k)
+                        for bit, col in ((abi.FLAG_IS_LC_SAFE, "is_lc_safe"), (abi.FLAG_IS_COLLABORATING, "is_collaborating"),
+                                         (abi.FLAG_COLLABORATE_ADJ, "collaborate_adj")):
+                            discrete(np.array_equal((fl & bit) != 0, gi[:, SI[col]] != 0), tr, k, (path, t, k, col))
                     if check_qp and rows.any():
                         # the reference solves in road.step order = descending pre-step x
                         xs_prev = (sub_f[s_at + k - 1][:, SF["x"]] if (s_at + k) > 0 else f0[:, SF["x"]])
-                        order = sorted(range(n), key=lambda j: -xs_prev[j])
-                        for j in order:
-                            assert rows[j] == qp_rows[q_at], (path, t, k, j, rows[j], qp_rows[q_at])
+                        for j in sorted(range(n), key=lambda j: -xs_prev[j]):
+                            discrete(rows[j] == qp_rows[q_loc], tr, k, (path, t, k, j, rows[j], qp_rows[q_loc]))
                             got_h = np.array([tr[k, abi.T["QP_H%d" % r], j] for r in range(rows[j])])
-                            e = max(abs(tr[k, abi.T["QP_A"], j] - qp_G[q_at, 0, 0]),
-                                    float(np.abs(got_h - qp_h[q_at, :rows[j]]).max()),
-                                    abs(tr[k, abi.T["QP_D"], j] - qp_x[q_at, 0]))
-                            mx["qp"] = max(mx["qp"], float(e))
-                            q_at += 1
+                            e = max(abs(tr[k, abi.T["QP_A"], j] - qp_G[q_loc, 0, 0]),
+                                    float(np.abs(got_h - qp_h[q_loc, :rows[j]]).max()),
+                                    abs(tr[k, abi.T["QP_D"], j] - qp_x[q_loc, 0]))
+                            step_mx["qp"] = max(step_mx["qp"], float(e))
+                            q_loc += 1
+                for name, col in (("X", "x"), ("Y", "y"), ("HEADING", "heading"), ("SPEED", "speed")):
+                    step_mx["state"] = max(step_mx["state"], float(np.abs(tr[k, abi.T[name]] - gf[:, SF[col]]).max()))
+                cols = [("ACT_STEER", "act_steer"), ("ACT_ACC", "act_acc")]
+                if is_v1:
+                    cols += [("SAFE_STEER", "safe_steer"), ("SAFE_ACC", "safe_acc")]
+                for name, col in cols:
+                    step_mx["action"] = max(step_mx["action"], float(np.abs(tr[k, abi.T[name]] - gf[:, SF[col]]).max()))
+            o = {k2: v[0].cpu().numpy() for k2, v in out.items()}
+            step_mx["obs"] = max(step_mx["obs"], float(np.abs(obs[0].cpu().numpy() - z["obs"][t]).max()))
+            step_mx["reward"] = max(step_mx["reward"], abs(float(o["reward"]) - z["reward"][t]),
+                                    float(np.abs(o["agents_rewards"] - z["agents_rewards"][t]).max()),
+                                    float(np.abs(o["regional_rewards"] - z["regional_rewards"][t]).max()))
+            step_mx["info"] = max(step_mx["info"], abs(float(o["average_speed"]) - z["average_speed"][t]),
+                                  abs(float(o["traffic_speed"]) - z["traffic_speed"][t]),
+                                  abs(float(o["min_headway"]) - z["min_headway"][t]))
+            discrete(bool(o["done"]) == bool(z["done"][t]), tr, 2, (path, t, "done"))
+            discrete(np.array_equal(o["agents_dones"].astype(bool), z["agents_dones"][t]), tr, 2, (path, t, "agents_dones"))
+            discrete(np.array_equal(o["action_mask"], z["action_mask"][t]), tr, 2, (path, t, "action_mask"))
+            if z["done"][t]:
+                assert abs(float(o["merge_percent"]) - z["merge_percent"][t]) <= 1e-9
+                assert bool(o["crashed"].any()) == meta["crashed"]
+            for key, v in step_mx.items():
+                discrete(v <= tol, tr, 2, (path, t, key, v))
+            mx = step_mx
+        except _KnifeEdge:
+            knife += 1
+            assert teacher_forcing, (path, t, "knife-edge flip without teacher forcing: trajectories diverge")
         s_at += nsub
-        o = {k2: v[0].cpu().numpy() for k2, v in out.items()}
-        mx["obs"] = max(mx["obs"], float(np.abs(obs[0].cpu().numpy() - z["obs"][t]).max()))
-        mx["reward"] = max(mx["reward"], abs(float(o["reward"]) - z["reward"][t]),
-                           float(np.abs(o["agents_rewards"] - z["agents_rewards"][t]).max()),
-                           float(np.abs(o["regional_rewards"] - z["regional_rewards"][t]).max()))
-        mx["info"] = max(mx["info"], abs(float(o["average_speed"]) - z["average_speed"][t]),
-                         abs(float(o["traffic_speed"]) - z["traffic_speed"][t]),
-                         abs(float(o["min_headway"]) - z["min_headway"][t]))
-        assert bool(o["done"]) == bool(z["done"][t]), (path, t)
-        assert np.array_equal(o["agents_dones"].astype(bool), z["agents_dones"][t]), (path, t)
-        assert np.array_equal(o["action_mask"], z["action_mask"][t]), (path, t)
-        if z["done"][t]:
-            assert abs(float(o["merge_percent"]) - z["merge_percent"][t]) <= 1e-9
-            assert bool(o["crashed"].any()) == meta["crashed"]
-        for key, v in mx.items():
-            assert v <= tol, (path, t, key, v)
-    if check_qp and meta["shield"] != "none":
-        assert q_at == len(qp_rows), (q_at, len(qp_rows))
+        q_at += nqp
+    assert q_at == len(qp_rows), (q_at, len(qp_rows))
+    assert knife <= max_knife_edges, (path, "knife-edge decisions", knife)
     env.close()
     err.update(mx)
+    err["knife_edges"] = knife
     return err

@@ -14,13 +14,40 @@ from marl_mass_amd import VecMergeEnv, _cabi as abi
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _portable_math():
+    """The oracle evaluates include/mm_math.h (as the kernels do): HIP-vs-oracle must be bit-equal."""
+    oracle_env.set_math_mode(1)
+    yield
+    oracle_env.set_math_mode(0)
+
+
+def test_math_bits_cpu_vs_gpu():
+    """Every elementary function + sqrt + division: identical bits on gfx950 and x86-64."""
+    clib, olib = _gpu_env(1, 2).clib, oracle_env.library()
+    g = torch.Generator().manual_seed(0)
+    n = 1 << 20
+    u = torch.rand(n, dtype=torch.float64, generator=g)
+    ranges = {0: (-8, 8), 1: (-8, 8), 2: (-1.2, 1.2), 3: (-4, 4), 4: (-1, 1), 5: (-20, 0.5), 6: (1e-6, 100),
+              7: (0, 1e6), 8: (-1e3, 1e3)}
+    x2 = (torch.rand(n, dtype=torch.float64, generator=g) * 50 + 0.01)
+    for fn, (lo, hi) in ranges.items():
+        x = (lo + (hi - lo) * u).contiguous()
+        yc = torch.zeros(n, dtype=torch.float64)
+        assert olib.lib.mm_math_eval(fn, n, x.data_ptr(), x2.data_ptr(), yc.data_ptr(), None) == 0
+        xg, x2g, yg = x.cuda(), x2.cuda(), torch.zeros(n, dtype=torch.float64, device="cuda:0")
+        assert clib.lib.mm_math_eval(fn, n, xg.data_ptr(), x2g.data_ptr(), yg.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(yg.cpu().view(torch.int64), yc.view(torch.int64)), "fn %d differs" % fn
+
+
 def _gpu_env(E, N, **kw):
     return VecMergeEnv(E, N, device="cuda:0", **kw)
 
 
 @pytest.mark.parametrize("path", episode_files(), ids=lambda p: os.path.basename(p)[:-4])
 def test_golden_tape(path):
-    err = replay(_gpu_env, path)
+    err = replay(_gpu_env, path, tol=1e-9, max_knife_edges=6)
     print(os.path.basename(path), json.dumps({k: float("%.3g" % v) for k, v in err.items()}))
 
 
@@ -67,7 +94,9 @@ def test_random_rollout_vs_oracle(env_id, safety, N, E, steps, eta, tau):
         m = max(float(v) for v in errs.values())
         worst = max(worst, m)
         assert m <= FLOAT_TOL, (t, {k: float(v) for k, v in errs.items()})
-    print("worst abs err %.3g over %d steps x %d envs" % (worst, steps, E))
+        # same elementary functions, same operation order, no contraction: every bit must agree
+        assert m == 0.0, (t, {k: float(v) for k, v in errs.items()})
+    print("bit-exact over %d steps x %d envs x %d agents" % (steps, E, N))
 
 
 def test_float32_obs_matches_float64():

@@ -78,6 +78,37 @@ def test_rotated_rectangles(units, lib):
 
 @pytest.mark.parametrize("path", episode_files(), ids=lambda p: os.path.basename(p)[:-4])
 def test_episode_tape(path):
-    """Full env.step parity: per-sub-step state, QP rows, obs, rewards, dones, info."""
-    err = replay(oracle_env.OracleEnv, path)
+    """Full env.step parity with the reference's own libm arithmetic: per-sub-step state, QP rows,
+    obs, rewards, dones, info -- agreement to rounding noise (1e-12 absolute on O(1e3) values)."""
+    oracle_env.set_math_mode(0)
+    err = replay(oracle_env.OracleEnv, path, tol=1e-12)
     print(os.path.basename(path), json.dumps({k: float("%.3g" % v) for k, v in err.items()}))
+
+
+@pytest.mark.parametrize("path", episode_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_episode_tape_portable_math(path):
+    """Same tapes with include/mm_math.h (the functions the HIP kernels evaluate) instead of libm:
+    identical flags / QP structure, floats within 1e-9.  The only tolerated discrete differences
+    are the shield's structural LC knife-edges (|margin| < 1e-9), counted and bounded."""
+    oracle_env.set_math_mode(1)
+    try:
+        err = replay(oracle_env.OracleEnv, path, tol=1e-9, max_knife_edges=6)
+    finally:
+        oracle_env.set_math_mode(0)
+    print(os.path.basename(path), json.dumps({k: float("%.3g" % v) for k, v in err.items()}))
+
+
+def test_portable_math_accuracy(lib):
+    """mm_math.h vs numpy/libm: <= 4 ulp on the argument ranges the env produces."""
+    rs = np.random.RandomState(1)
+    cases = [(0, np.sin, rs.uniform(-8, 8, 200000)), (1, np.cos, rs.uniform(-8, 8, 200000)),
+             (2, np.tan, rs.uniform(-1.1, 1.1, 200000)), (3, np.arctan, rs.uniform(-3, 3, 200000)),
+             (4, np.arcsin, np.concatenate([rs.uniform(-1, 1, 200000), [1.0, -1.0, 0.0]])),
+             (5, np.exp, rs.uniform(-12, 0, 200000)), (6, np.log, rs.uniform(1e-3, 80, 200000))]
+    for fn, ref, x in cases:
+        x = np.ascontiguousarray(x)
+        y = np.zeros_like(x)
+        assert lib.mm_math_eval(fn, len(x), _p(x), None, _p(y), None) == 0
+        r = ref(x)
+        ulp = np.spacing(np.abs(r))
+        assert float(np.max(np.abs(y - r) / ulp)) <= 4.0, fn
