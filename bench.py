@@ -37,7 +37,7 @@ def cpu_baseline(args, env_id, cfg, kw):
     """Times the CPU oracle (the C restatement, `kind: port`) on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import oracle_env
-    threads = oracle_env.library().lib.orc_set_threads(args.cpu_threads or (os.cpu_count() or 1))
+    threads = oracle_env.library().lib.orc_set_threads(args.cpu_threads or min(16, os.cpu_count() or 1))
     E, N, K = args.cpu_envs, args.agents, args.cpu_steps
     env = oracle_env.OracleEnv(E, N, env_id=env_id, config=cfg, **kw)
     env.reset()
@@ -64,8 +64,8 @@ def main():
     ap.add_argument("--env-id", default="merge-multi-agent-v1")
     ap.add_argument("--obs-f64", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-envs", type=int, default=8192)
-    ap.add_argument("--cpu-steps", type=int, default=100)
+    ap.add_argument("--cpu-envs", type=int, default=16384)
+    ap.add_argument("--cpu-steps", type=int, default=200)
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 
@@ -80,7 +80,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from marl_mass_amd import VecMergeEnv
+    from marl_mass_amd import VecMergeEnv, reduce_rollout_metrics
     E, N = args.envs, args.agents
     cfg = {"safety_guarantee": SHIELDS[args.shield], "HEADWAY_TIME": 0.5 if args.shield != "none" else 1.2}
     kw = dict(cbf_eta=0.03125 if args.shield != "none" else 0.0, cbf_tau=cfg["HEADWAY_TIME"], seed=1000,
@@ -118,10 +118,7 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # end-of-rollout metric reduction: the only collective of the path
-        dist.all_reduce(metrics[:7], op=dist.ReduceOp.SUM)
-        mn = metrics[7:8].clone()
-        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
-        metrics[7] = mn[0]
+        reduce_rollout_metrics(metrics)
     elapsed = float(tmax[0])
     m = metrics.cpu().tolist()
 

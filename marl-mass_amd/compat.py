@@ -102,7 +102,13 @@ class MergeEnvCompat(object):
         self.done = False
         self.n_merge = 0
         self.T = int(self.config["duration"] * self.config["policy_frequency"])
-        self.reset()  # abstract.py:86
+        try:
+            self.reset()  # abstract.py:86 (the constructor already resets)
+        except NotImplementedError:
+            # default configs ask for mixed traffic (HDVs), which this engine does not simulate yet:
+            # stay un-initialised until the caller has written env.config[...] (run_mappo.py:145-171)
+            # and calls reset(); step() before that raises like abstract.py:454-455.
+            self.road, self.controlled_vehicles = None, []
 
     unwrapped = property(lambda self: self)
 

@@ -178,6 +178,28 @@ class BatchedMergeEnv(object):
             pass
 
 
+def reduce_rollout_metrics(metrics):
+    """The path's only collective: SUM the 7 accumulators and MIN the headway over ranks.
+    RCCL on GPUs (backend "nccl"), gloo on CPU; 64 bytes, latency-bound.  In place; returns metrics."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        sums, mn = metrics[:7].clone(), metrics[7:8].clone()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        metrics[:7] = sums
+        metrics[7:8] = mn
+    return metrics
+
+
+def shard_range(E_total, rank, world):
+    """Contiguous env shard of a rank: (first_env, count).  Envs are independent episodes, so the
+    batch partitions with no data-path exchange; RNG streams are keyed by the global env index."""
+    base, rem = divmod(int(E_total), int(world))
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
 _HIP = None
 
 

@@ -1,0 +1,121 @@
+"""Host-side mirror of the reference's Env interface (MergeEnvCompat), driven on CPU through the
+oracle backend: reset RNG parity with the reference and step() tuple parity with the golden tapes."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_env
+from golden_util import GOLDEN, load_episode
+from marl_mass_amd import compat
+from marl_mass_amd import _cabi as abi
+
+
+def _factory(**kw):
+    return oracle_env.OracleEnv(**kw)
+
+
+@pytest.fixture(scope="module")
+def resets():
+    return json.load(open(os.path.join(GOLDEN, "reset.json")))
+
+
+def test_reset_matches_reference_fixed_counts(resets):
+    """abstract.py:176-209 + merge_env_v1.py:265-364: same global-RNG draws -> same spawn, bit for bit."""
+    for row in resets["fixed"]:
+        env = compat.MergeEnvCompat(row["env"], backend_factory=_factory)
+        env._num_vehicles = lambda num_CAV=0, n=row["n"]: (n, 0)  # the fixture forced the count the same way
+        obs, avail = env.reset(is_training=False, testing_seeds=row["seed"])
+        f = np.array(row["f"])
+        got = env._b.f64[:5, 0, :row["n"]].numpy().T
+        np.testing.assert_array_equal(got, f)
+        ints = np.array(row["i"])
+        np.testing.assert_array_equal(env._b.u8[abi.B["LANE"], 0, :row["n"]].numpy(), ints[:, 0])
+        np.testing.assert_array_equal(env._b.u8[abi.B["SPEED_INDEX"], 0, :row["n"]].numpy(), ints[:, 2])
+        assert env.n_merge == row["n_merge"]
+        np.testing.assert_allclose(obs, np.array(row["obs"]), rtol=0, atol=1e-12)
+        assert obs.shape == (row["n"], env.n_s) and avail.shape == (row["n"], 5)
+
+
+def test_reset_matches_reference_drawn_counts(resets):
+    """merge_env_v1.py:180-211: the vehicle-count draw for traffic_density 1..3, CAV-only traffic."""
+    for row in resets["drawn"]:
+        env = compat.MergeEnvCompat("merge-multi-agent-v1", backend_factory=_factory)
+        env.config["traffic_density"] = row["td"]
+        env.config["traffic_type"] = "cav"
+        env.reset(is_training=False, testing_seeds=row["seed"])
+        assert len(env.controlled_vehicles) == row["n"] and env.n_merge == row["n_merge"]
+        np.testing.assert_array_equal(env._b.f64[:5, 0, :row["n"]].numpy().T, np.array(row["f"]))
+
+
+def test_training_seed_increments():
+    env = compat.MergeEnvCompat("merge-multi-agent-v1", backend_factory=_factory)
+    env.config["traffic_type"] = "cav"
+    s0 = env.seed
+    env.reset()
+    assert env.seed == s0 + 1  # abstract.py:190
+
+
+@pytest.mark.parametrize("name", ["ep_v0_none_N4_s25", "ep_v1_mass_N8_s0", "ep_v1_hss_N4_s50"])
+def test_step_tuple_matches_golden(name):
+    """The (obs, reward, done, info) tuple of MergeEnv.step through the adapter, free-running."""
+    z, meta = load_episode(os.path.join(GOLDEN, name + ".npz"))
+    compat.CBFType.GAMMA_B, compat.CBFType.TAU = meta["eta"], meta["headway_time"]
+    env = compat.MergeEnvCompat(meta["env_id"], backend_factory=_factory)
+    env.config.update({"safety_guarantee": meta["shield"], "HEADWAY_TIME": meta["headway_time"],
+                       "action_masking": False, "traffic_type": "cav", "mixed_traffic": False})
+    env._num_vehicles = lambda num_CAV=0: (meta["n"], 0)
+    obs, avail = env.reset(is_training=False, testing_seeds=meta["seed"])
+    np.testing.assert_allclose(obs, z["obs0"], rtol=0, atol=1e-12)
+    assert env.n_s == meta["n_s"] and env.T == 100 and len(env.controlled_vehicles) == meta["n"]
+    for t in range(meta["steps"]):
+        obs, reward, done, info = env.step(tuple(int(a) for a in z["actions"][t]))
+        np.testing.assert_allclose(obs, z["obs"][t], rtol=0, atol=1e-9)
+        assert abs(reward - z["reward"][t]) <= 1e-9 and done == bool(z["done"][t])
+        np.testing.assert_allclose(info["regional_rewards"], z["regional_rewards"][t], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(info["agents_rewards"], z["agents_rewards"][t], rtol=0, atol=1e-9)
+        assert info["agents_dones"] == tuple(bool(d) for d in z["agents_dones"][t])
+        assert abs(info["average_speed"] - z["average_speed"][t]) <= 1e-9
+        assert abs(info["min_headway"] - z["min_headway"][t]) <= 1e-9
+        assert info["vehicle_speed"].shape == (t + 1, meta["n"])
+    assert done and abs(info["merge_percent"] - z["merge_percent"][meta["steps"] - 1]) <= 1e-9
+    assert env.is_crashed() == meta["crashed"]
+    assert env.controlled_vehicles[0].lane_index in abi.LANE_INDEX
+
+
+def test_error_behaviour():
+    with pytest.raises(ValueError):
+        compat.cbf_factory("nope", action_size=2, action_bound=[(0, 1), (-1, 1)], vehicle_size=[5, 2], vehicle_lane=0)
+    with pytest.raises(ValueError):
+        compat.safety_layer("nope", {}, None, 1 / 15)
+    with pytest.raises(ValueError):
+        compat.MergeEnvCompat("merge-v1", backend_factory=_factory)
+    env = compat.MergeEnvCompat("merge-multi-agent-v1", backend_factory=_factory)
+    env.config["safety_guarantee"] = "cbf-avlon"  # unknown CBF type: ValueError like decentral_layer.py:817
+    with pytest.raises(ValueError):
+        env.reset()
+
+
+def test_cbf_control_barrier_shim_matches_golden_qp():
+    """cbf_factory(...).control_barrier (cbf.py:110-161) packs the same G/h the reference logged."""
+    z, meta = load_episode(os.path.join(GOLDEN, "ep_v1_mass_N4_s0.npz"))
+    solver = oracle_env.OracleEnv(1, 2)
+    dt = 1 / 15
+    # rebuild one QP from its logged rows: a = G[0,0], bounds from h1/h2 with u_ll[0] = 20
+    k = int(np.argmax(z["qp_x"][:, 0] < -1e-3))
+    G, h = z["qp_G"][k], z["qp_h"][k]
+    u0 = 20.0
+    cbf = compat.cbf_factory("cav", solver=solver, action_size=2, action_bound=[(u0 - h[2], u0 + h[1]), (-4 * np.pi, 4 * np.pi)],
+                             vehicle_size=[5.0, 2.0], vehicle_lane=0)
+    # choose x / f / g / u so that the assembled row equals the logged one: p_lon.x = 0, u_ol = 0
+    compat.CBFType.GAMMA_B = 0.0
+    g = np.diag([G[0, 0], dt, dt, dt, dt, dt, dt, dt])
+    x = np.zeros(8)
+    cbf.safe_dists = [0, 0, 0]
+    u_ll = np.array([u0, 0, 0, 0, 0, 0, 0, 0.0])
+    u_safe = cbf.control_barrier(u_ll, x.copy(), g, x, dt)
+    h0 = -G[0, 0] * u0  # what the shim's row evaluates to for this construction
+    d = min(0.0, h0 / G[0, 0])
+    d = min(max(d, -h[2]), h[1])
+    assert abs(u_safe[0] - (u0 + d)) <= 1e-12

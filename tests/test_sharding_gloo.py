@@ -1,0 +1,76 @@
+"""N>1 path on CPU: two gloo ranks each own half of the env batch (oracle backend).  Sharding must
+not change any env (RNG streams are keyed by global env id) and the metric all-reduce must equal
+the single-process accumulator."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+E, N, STEPS = 48, 4, 104
+KW = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
+          cbf_eta=0.03125, cbf_tau=0.5, seed=77, auto_reset=True)
+
+
+def _tape():
+    g = torch.Generator().manual_seed(5)
+    p = torch.tensor([0.1, 0.5, 0.2, 0.1, 0.1])
+    return [torch.multinomial(p, E * N, True, generator=g).view(E, N).int() for _ in range(STEPS)]
+
+
+def _run(env, actions):
+    m = env.enable_metrics()
+    env.reset()
+    for a in actions:
+        env.step(a)
+    return m
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (REPO, os.path.join(REPO, "oracle")):
+        sys.path.insert(0, p)
+    import oracle_env
+    from marl_mass_amd import reduce_rollout_metrics, shard_range
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oracle_env.library().lib.orc_set_threads(1)
+    first, count = shard_range(E, rank, world)
+    env = oracle_env.OracleEnv(count, N, first_env=first, **KW)
+    m = _run(env, [a[first:first + count].contiguous() for a in _tape()])
+    reduce_rollout_metrics(m)
+    torch.save({"f64": env.f64.clone(), "u8": env.u8.clone(), "i32": env.env_i32.clone(), "metrics": m.clone(),
+                "first": first, "count": count}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shards_equal_single_batch(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    import oracle_env
+    oracle_env.library().lib.orc_set_threads(1)
+    full = oracle_env.OracleEnv(E, N, **KW)
+    m = _run(full, _tape())
+    parts = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r)) for r in range(2)]
+    for part in parts:
+        sl = slice(part["first"], part["first"] + part["count"])
+        assert torch.equal(part["f64"].nan_to_num(), full.f64[:, sl].nan_to_num())
+        assert torch.equal(part["u8"], full.u8[:, sl]) and torch.equal(part["i32"], full.env_i32[:, sl])
+    # every rank holds the reduced metrics; sums differ from the single-process order only by fp reassociation
+    for part in parts:
+        assert torch.allclose(part["metrics"][:7], m[:7], rtol=1e-12, atol=0)
+        assert float(part["metrics"][7]) == float(m[7])
+    assert float(m[4]) == E * STEPS and float(m[6]) >= E  # env-steps counted, every episode finished once
+
+
+def test_shard_range_covers_batch():
+    from marl_mass_amd import shard_range
+    for total, world in ((65536, 8), (10, 3), (7, 8)):
+        got = [shard_range(total, r, world) for r in range(world)]
+        assert sum(c for _, c in got) == total
+        assert all(got[i][0] + got[i][1] == got[i + 1][0] for i in range(world - 1))
