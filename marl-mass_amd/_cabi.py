@@ -44,7 +44,7 @@ class MMConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("env_kind", C.c_int32), ("shield", C.c_int32),
                 ("simulation_frequency", C.c_int32), ("policy_frequency", C.c_int32),
                 ("duration", C.c_int32), ("action_masking", C.c_int32), ("auto_reset", C.c_int32),
-                ("obs_f64", C.c_int32), ("reserved0", C.c_int32),
+                ("obs_f64", C.c_int32), ("debug_flags", C.c_int32),
                 ("collision_reward", C.c_double), ("high_speed_reward", C.c_double),
                 ("headway_cost", C.c_double), ("headway_time", C.c_double),
                 ("merging_lane_cost", C.c_double), ("reward_speed_lo", C.c_double),
@@ -91,7 +91,7 @@ def default_env_config(env_id):
     return cfg
 
 
-def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0):
+def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0, debug_flags=0):
     """env.config dict (+ CBFType.GAMMA_B / CBFType.TAU, run_mappo.py:138-139) -> MMConfig."""
     c = MMConfig()
     c.abi_version = MM_ABI_VERSION
@@ -105,6 +105,7 @@ def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs
     c.action_masking = int(bool(config.get("action_masking", False)))
     c.auto_reset = int(bool(auto_reset))
     c.obs_f64 = int(bool(obs_f64))
+    c.debug_flags = int(debug_flags)
     c.collision_reward = float(config["COLLISION_REWARD"])
     c.high_speed_reward = float(config["HIGH_SPEED_REWARD"])
     c.headway_cost = float(config["HEADWAY_COST"])

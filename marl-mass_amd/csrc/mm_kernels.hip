@@ -21,12 +21,14 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "mm_device.h"
 
 using namespace mm;
 
 struct DevCfg {
-  int env_kind, shield, nsub, T, action_masking, auto_reset, obs_f64, N;
+  int env_kind, shield, nsub, T, action_masking, auto_reset, obs_f64, N, debug_flags;
   double dt, collision_reward, high_speed_reward, headway_cost, headway_time, merging_lane_cost;
   double rs_lo, rs_hi, eta, tau;
 };
@@ -51,10 +53,44 @@ struct Veh {
 // wave helpers (64 lanes; an env group never straddles a wave)
 // ------------------------------------------------------------------------------------------------
 MM_DEV int lane_id() { return threadIdx.x & 63; }
+// dynamic-source shuffles go through the LDS crossbar (ds_bpermute_b32)
 MM_DEV double shfl_d(double v, int src) { return __shfl(v, src, 64); }
 MM_DEV int shfl_i(int v, int src) { return __shfl(v, src, 64); }
-MM_DEV double shflx_d(double v, int m) { return __shfl_xor(v, m, 64); }
-MM_DEV int shflx_i(int v, int m) { return __shfl_xor(v, m, 64); }
+
+// Partner exchange inside an env group: lane ^ M for a compile-time M < 16, built from DPP row
+// permutations (v_mov_b32_dpp: no LDS round trip, a few cycles) instead of ds_bpermute:
+//   M = 1,2,3 quad_perm; 7 row_half_mirror; 8 row_ror:8; 15 row_mirror; the rest are compositions.
+// Every lane of the wave must be active where these are used (they sit in uniform control flow).
+template <int M>
+MM_DEV int dppx_i(int v) {
+  static_assert(M >= 1 && M <= 15, "xor mask within a 16-lane DPP row");
+  if constexpr (M == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);        // quad_perm:[1,0,3,2]
+  else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);   // quad_perm:[2,3,0,1]
+  else if constexpr (M == 3) return __builtin_amdgcn_update_dpp(0, v, 0x1B, 0xF, 0xF, false);   // quad_perm:[3,2,1,0]
+  else if constexpr (M == 7) return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+  else if constexpr (M == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, false);  // row_ror:8
+  else if constexpr (M == 15) return __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false); // row_mirror
+  else if constexpr (M < 7) return dppx_i<7>(dppx_i<7 - M>(v));
+  else if constexpr (M < 12) return dppx_i<8>(dppx_i<M - 8>(v));
+  else return dppx_i<15>(dppx_i<15 - M>(v));
+}
+template <int M>
+MM_DEV double dppx_d(double v) {
+  long long b = __double_as_longlong(v);
+  int lo = dppx_i<M>((int)(unsigned)(b & 0xFFFFFFFFll)), hi = dppx_i<M>((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// compile-time loop over the partners a ^ 1 .. a ^ (G-1) of a group
+template <int M, int G, class F>
+MM_DEV void for_partners_impl(F &f) {
+  if constexpr (M < G) {
+    f(std::integral_constant<int, M>{});
+    for_partners_impl<M + 1, G>(f);
+  }
+}
+template <int G, class F>
+MM_DEV void for_partners(F f) { for_partners_impl<1, G>(f); }
+
 template <int G>
 MM_DEV unsigned group_ballot(bool p, int gb) {
   unsigned long long b = __ballot(p);
@@ -70,8 +106,10 @@ MM_DEV void atomic_min_d(double *addr, double val) {  // CAS loop: valid for any
 }
 template <int G>
 MM_DEV double group_min_d(double v) {
-#pragma unroll
-  for (int m = 1; m < G; m <<= 1) v = fmin(v, shflx_d(v, m));
+  if constexpr (G >= 2) v = fmin(v, dppx_d<1>(v));
+  if constexpr (G >= 4) v = fmin(v, dppx_d<2>(v));
+  if constexpr (G >= 8) v = fmin(v, dppx_d<7>(v));  // after xor 1,2 every quad is uniform: xor 7 == xor 4
+  if constexpr (G >= 16) v = fmin(v, dppx_d<8>(v));
   return v;
 }
 
@@ -172,7 +210,7 @@ MM_DEV void corner_flags(double x, double y, double h, int lane, bool &offL, boo
 // safe_controller.py:151-172): everything that does not depend on the acceleration.
 struct Cand {
   double x, y, h, gvx, cpsi;
-  int lane;
+  int lane, nl;  // closest lane of the post-state and its next_lane
   bool offL, offR;
 };
 template <int KIND, bool SHIELDED>
@@ -187,7 +225,11 @@ MM_DEV Cand predict(const Veh &v, double steer, double dt) {
   c.lane = closest_lane(c.x, c.y, c.h);  // on_state_update kinematics.py:154-159
   c.cpsi = (KIND == MM_ENV_V1) ? mmm_cos(c.h) : 0.0;
   c.offL = c.offR = false;
-  if (SHIELDED) corner_flags(c.x, c.y, c.h, c.lane, c.offL, c.offR);
+  c.nl = 0;
+  if (SHIELDED) {
+    corner_flags(c.x, c.y, c.h, c.lane, c.offL, c.offR);
+    c.nl = next_lane(c.lane, c.x, c.y);
+  }
   return c;
 }
 
@@ -259,37 +301,40 @@ MM_DEV int spawn_vehicle(Veh &v, int a, int N, uint64_t seed, uint32_t episode) 
 // ------------------------------------------------------------------------------------------------
 // observation (envs/common/observation.py:181-273) + action mask (abstract.py:219-240)
 // ------------------------------------------------------------------------------------------------
-template <int G, int KIND, typename OBS_T>
-MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, bool valid, OBS_T *obs,
+template <int G, int KIND>
+MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, bool valid, void *obs,
                     uint8_t *avail) {
   constexpr int F = (KIND == MM_ENV_V1) ? 6 : 5;
-  const double cps = mmm_cos(v.h), sps = mmm_sin(v.h);
+  double sps, cps;
+  mmm_sincos(v.h, &sps, &cps);
   const double vx = v.v * cps, vy = v.v * sps;  // Vehicle.velocity kinematics.py:215-217
   const double sx = lane_sx(v.lane);
+  // pass 1: sort keys of close_vehicles_to (road.py:257-267): |lane_distance_to|, inf if not within 180 m
   double key[G];
   key[0] = 0;
-#pragma unroll
-  for (int m = 1; m < G; m++) {
-    double px = shflx_d(v.x, m), py = shflx_d(v.y, m);
-    bool pp = shflx_i((int)v.present, m) != 0;
+  for_partners<G>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    double px = dppx_d<m>(v.x), py = dppx_d<m>(v.y);
+    bool pp = dppx_i<m>((int)v.present) != 0;
     double dx = px - v.x, dy = py - v.y;
-    bool close = pp && sqrt(dx * dx + dy * dy) < kPerception;  // road.py:259-262
-    key[m] = close ? fabs((px - sx) - (v.x - sx)) : INFINITY;   // |lane_distance_to| kinematics.py:161-173
-  }
+    bool close = pp && sqrt(dx * dx + dy * dy) < kPerception;
+    key[m] = close ? fabs((px - sx) - (v.x - sx)) : INFINITY;
+  });
   double row[4][F - 1];
   bool have[4] = {false, false, false, false};
 #pragma unroll
   for (int q = 0; q < 4; q++)
 #pragma unroll
     for (int f = 0; f < F - 1; f++) row[q][f] = 0;
-#pragma unroll
-  for (int m = 1; m < G; m++) {
-    int rank = 0;  // position in sorted(key=|lane distance|) (stable: ties keep creation order)
+  // pass 2: the 4 nearest in stable order become rows 1..4
+  for_partners<G>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    int rank = 0;
 #pragma unroll
     for (int m2 = 1; m2 < G; m2++)
       if (m2 != m) rank += (key[m2] < key[m] || (key[m2] == key[m] && (a ^ m2) < (a ^ m))) ? 1 : 0;
-    double px = shflx_d(v.x, m), py = shflx_d(v.y, m), pvx = shflx_d(vx, m), pvy = shflx_d(vy, m);
-    double ph = (KIND == MM_ENV_V1) ? shflx_d(v.h, m) : 0.0;
+    double px = dppx_d<m>(v.x), py = dppx_d<m>(v.y), pvx = dppx_d<m>(vx), pvy = dppx_d<m>(vy);
+    double ph = (KIND == MM_ENV_V1) ? dppx_d<m>(v.h) : 0.0;
     bool use = key[m] < INFINITY;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -299,28 +344,35 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
         if (KIND == MM_ENV_V1) row[q][F - 2] = ph;
       }
     }
-  }
+  });
   if (valid && obs) {
     // normalize_obs :181-193 via utils.lmap :16-18 (no clip); ranges :171-176, :238-239
     const double lo[5] = {-5.0 * 30, -12, -1.5 * 30, -1.5 * 30, -kPi / 2};
     const double hi[5] = {5.0 * 30, 12, 1.5 * 30, 1.5 * 30, kPi / 2};
-    OBS_T *o = obs + i * (5 * F);
-    if (!v.present) {
+    double o[5 * F];
 #pragma unroll
-      for (int k = 0; k < 5 * F; k++) o[k] = (OBS_T)0;
-    } else {
+    for (int k = 0; k < 5 * F; k++) o[k] = 0;
+    if (v.present) {
       const double ego[5] = {v.x, v.y, vx, vy, v.h};
-      o[0] = (OBS_T)1;
+      o[0] = 1;
 #pragma unroll
-      for (int f = 0; f < F - 1; f++) o[1 + f] = (OBS_T)(-1 + (ego[f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f]));
+      for (int f = 0; f < F - 1; f++) o[1 + f] = -1 + (ego[f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f]);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        o[(q + 1) * F] = have[q] ? (OBS_T)1 : (OBS_T)0;
+        o[(q + 1) * F] = have[q] ? 1 : 0;
 #pragma unroll
         for (int f = 0; f < F - 1; f++)
-          o[(q + 1) * F + 1 + f] =
-              have[q] ? (OBS_T)(-1 + (row[q][f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f])) : (OBS_T)0;
+          o[(q + 1) * F + 1 + f] = have[q] ? (-1 + (row[q][f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f])) : 0;
       }
+    }
+    if (c.obs_f64) {
+      double *dst = (double *)obs + i * (5 * F);
+#pragma unroll
+      for (int k = 0; k < 5 * F; k++) dst[k] = o[k];
+    } else {
+      float *dst = (float *)obs + i * (5 * F);
+#pragma unroll
+      for (int k = 0; k < 5 * F; k++) dst[k] = (float)o[k];
     }
   }
   // action mask: with masking on, the reference's `[[0]*n_a]*n` aliases every row (abstract.py:202,475)
@@ -347,9 +399,150 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
 }
 
 // ------------------------------------------------------------------------------------------------
+// CBF shield of ONE vehicle given its selected neighbours (safe_action_hss / safe_action_mass,
+// decentral_layer.py:290-518 / :521-764; rows of cbf.py:262-322,374-422; exact-KKT QP).
+// Scalar form of the reference's 8-vectors: only the x / speed components enter the CBF rows.
+// ------------------------------------------------------------------------------------------------
+struct Neigh {  // the three slots of multi_agent_state (:85-257) after the obstacle overrides
+  bool has_ol, has_oa, has_oar, constrain_adj;
+  double ol_x, ol_vx, ol_acc, ol_g;  // leader: state_hist[-2].x / .vx, its action and g.vx (MASS)
+  double oa_x, oa_vx, oa_acc, oa_g;  // front adjacent
+  double oar_x, oar_vx;              // rear adjacent: current to_dict()
+};
+struct ShieldOut {
+  double acc, us0;  // derived acceleration, u_safe[0]
+  bool veto;        // "Avoiding lane change" (:501-506 / :739-744)
+  int flags;
+  QpTrace qt;
+};
+template <bool MASS>
+MM_DEV unsigned obstacle_override(Neigh &nb, double x, double y) {  // decentral_layer.py:213-246
+  unsigned replaced = 0;  // bit0: leader slot, bit1: adjacent slot now hold the obstacle at (420, 4)
+  if (!(x > kObstX)) {
+    const double ady = fabs(kObstY - y);
+    if ((!nb.has_ol || kObstX <= nb.ol_x) && ady <= 2) {
+      nb.has_ol = true; nb.ol_x = kObstX; nb.ol_vx = 0.0;
+      if (MASS) { nb.ol_acc = 0; nb.ol_g = 0; }
+      replaced |= 1u;
+    }
+    if ((!nb.has_oa || kObstX <= nb.oa_x) && (2 < ady && ady <= 4)) {
+      nb.has_oa = true; nb.oa_x = kObstX; nb.oa_vx = 0.0;
+      if (MASS) { nb.oa_acc = 0; nb.oa_g = 0; nb.constrain_adj = false; }
+      replaced |= 2u;
+    }
+  }
+  return replaced;
+}
+template <bool MASS>
+MM_DEV ShieldOut shield_eval(const DevCfg &c, const Veh &v, double cpsi, bool offL, bool offR, const Neigh &nb) {
+  const double dt = c.dt, eta = c.eta;
+  ShieldOut o;
+  double v_min = v.v + kLcMinAcc * dt;
+  if (MASS) v_min = v_min > 0 ? v_min : 0;  // :798
+  const double v_max = v.v + kLcMaxAcc * dt;
+  double evx = v.v * cpsi;
+  evx = evx > 1 ? evx : 1;  // :307-309
+  const double x_e = v.x;
+  const double x_ol = nb.has_ol ? nb.ol_x : x_e + kPerception + 1;
+  const double x_oa = nb.has_oa ? nb.oa_x : x_e + kPerception + 1;
+  const double x_oar = nb.has_oar ? nb.oar_x : x_e - kPerception - 1;
+  const double g0 = v.gvx * dt;
+  const double g2 = MASS ? nb.ol_g * dt : 1 * dt;
+  const double g4 = MASS ? nb.oa_g * dt : 1 * dt;
+  const double g6 = 1 * dt;
+  double sv_oar = nb.has_oar ? nb.oar_vx : 0;
+  sv_oar = sv_oar + kCbfAccHi * dt;
+  sv_oar = sv_oar > 1 ? sv_oar : 1;
+  const double buffer = (kCbfAccHi + 0.1) * dt * c.tau;
+  const double sd0 = evx * c.tau + kVehLength + buffer;
+  const double sd2 = sv_oar * c.tau + kVehLength + buffer;
+  // simplified_control (:60-77)
+  double u0 = evx + v.act_acc * dt; u0 = u0 > 0 ? u0 : 0;
+  double u2 = 0, u4 = 0, u6 = 0;
+  if (nb.has_ol) { u2 = nb.ol_vx + nb.ol_acc * dt; u2 = u2 > 0 ? u2 : 0; }
+  if (nb.has_oa) { u4 = nb.oa_vx + nb.oa_acc * dt; u4 = u4 > 0 ? u4 : 0; }
+  if (nb.has_oar) { u6 = nb.oar_vx + kCbfAccHi * dt; u6 = u6 > 0 ? u6 : 0; }
+  const bool cadj = MASS && nb.constrain_adj;
+  const double q_lon = -kVehLength - sd0;
+  double q_lona = -kVehLength - sd0;
+  const double q_lonr = -kVehLength - sd2;
+  if (cadj) q_lona = -kVehLength - sd0 - kAdjBuffer;
+  const double px_lon = x_ol - x_e, px_lona = x_oa - x_e, px_lonr = x_e - x_oar;
+  const double h0 = px_lon + (eta - 1) * px_lon + eta * q_lon + (-(g0 * u0) + g2 * u2);
+  const double h1 = v_max - u0;
+  const double h2 = -v_min + u0;
+  double h3 = __builtin_nan(""), hc = h0;
+  if (cadj) {
+    h3 = px_lona + (eta - 1) * px_lona + eta * q_lona + (-(g0 * u0) + g4 * u4);
+    hc = h3 < h0 ? h3 : h0;
+  }
+  // exact KKT point of min 1/2(d^2 + e^2 + 1e18 s^2) s.t. a d - s <= hc, lo <= d <= hi
+  double d;
+  if (g0 > 0) d = fmin(0.0, hc / g0);
+  else if (g0 < 0) d = fmax(0.0, hc / g0);
+  else d = 0.0;
+  d = fmin(fmax(d, -h2), h1);
+  double us0 = u0 + d;
+  // is_lc_allowed (cbf.py:324-339)
+  const double hls_lona = px_lona + q_lona;
+  const double hlds_lona = px_lona + ((-g0) * us0 + g4 * u4) + q_lona;
+  const double hls_lonr = px_lonr + q_lonr;
+  const double hlds_lonr = px_lonr + (g0 * us0 + (-g6) * u6) + q_lonr;
+  const double inv_lona = hlds_lona + (eta - 1) * hls_lona, inv_lonr = hlds_lonr + (eta - 1) * hls_lonr;
+  const bool lc_allowed = ((hls_lona >= 0) && inv_lona >= 0) && ((hls_lonr >= 0) && inv_lonr >= 0);
+  int fl = v.flags & MM_FLAG_COLLABORATE_ADJ;
+  if (cadj) fl |= MM_FLAG_IS_COLLABORATING;
+  bool veto;
+  if (!MASS) {
+    veto = !lc_allowed;
+  } else {
+    const bool can_abort_lc = !offL && !offR;  // :728-736 on the pre-step pose
+    veto = can_abort_lc && !lc_allowed;
+    if (!veto && (v.hl == 2 || v.hl == 0) && v.v < kStoppingSpeed) us0 = u0;  // :746-750
+    if (inv_lona >= -1e-6) fl |= MM_FLAG_COLLABORATE_ADJ;  // can_collaborate_adj cbf.py:424-430
+    else fl &= ~MM_FLAG_COLLABORATE_ADJ;
+  }
+  if (!veto) fl |= MM_FLAG_IS_LC_SAFE;
+  o.acc = (us0 - evx) / dt;  // derived_acceleration :80-82
+  o.us0 = us0; o.veto = veto; o.flags = fl;
+  o.qt.rows = cadj ? 4 : 3; o.qt.a = g0; o.qt.h0 = h0; o.qt.h1 = h1; o.qt.h2 = h2; o.qt.h3 = h3; o.qt.d = d;
+  o.qt.margin = fmin(fmin(hls_lona, inv_lona), fmin(hls_lonr, inv_lonr));
+  return o;
+}
+
+// Relation of vehicle `o` (as the ego currently sees it) to the ego: the branch conditions of the
+// loop in multi_agent_state (decentral_layer.py:104-211).  cls: 0 none, 1 leader, 2 front-adjacent,
+// 3 rear-adjacent.  cflag: constrain_adj candidate = the relevant front corner of `o` left its lane.
+struct Rel {
+  double key;  // |ego.lane_distance_to(o)| or inf when o is not within the perception distance
+  int cls;
+  bool cflag;
+};
+MM_DEV Rel relate(double ex, double ey, int elane, int enl, bool other, double ox, double oy, double oh, int olane,
+                  int onl, bool ooffL, bool ooffR) {
+  Rel r;
+  const double dx = ox - ex, dy = oy - ey;
+  const bool close = other && sqrt(dx * dx + dy * dy) < kPerception;  // road.py:259-262
+  const double esx = lane_sx(elane);
+  const double ld = (ox - esx) - (ex - esx);  // kinematics.py:161-173
+  r.key = close ? fabs(ld) : INFINITY;
+  const int v_a = adj_lane(elane, enl, olane), a_v = adj_lane(olane, onl, elane);
+  const bool appr = !(ld < 0) && fabs(dy) <= 3.5 && (dy < 0 ? oh > 0.037 : oh < -0.037);  // :46-57
+  const bool adj = !appr && (v_a != 0 || a_v != 0);
+  const bool same = (elane == olane) || (olane == enl);  // is_same_lane :15-20
+  r.cls = 0;
+  if (close) {
+    if (adj) r.cls = ld < 0 ? 3 : 2;
+    else if ((same || appr) && ld > 0) r.cls = 1;
+  }
+  r.cflag = (v_a == -1 || a_v == 1) ? ooffL : ooffR;  // :146-152 which front corner of `o`
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // the fused step kernel
 // ------------------------------------------------------------------------------------------------
-template <int G, int KIND, int SHIELD, typename OBS_T>
+template <int G, int KIND, int SHIELD>
 __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
                                                    MMStepOut out, double *metrics) {
   constexpr bool LC = (KIND == MM_ENV_V1);
@@ -395,14 +588,6 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
       mdp_act<KIND>(v, -1);                              // road.act road.py:269-278
       clip_actions<KIND>(v);
     }
-    // Road.step order: sorted by x descending, stable (road.py:286)
-    int rank = 0;
-#pragma unroll
-    for (int m = 1; m < G; m++) {
-      double px = shflx_d(v.x, m);
-      bool pp = shflx_i((int)v.present, m) != 0;
-      rank += (pp && (px > v.x || (px == v.x && (a ^ m) < a))) ? 1 : 0;
-    }
     // predicted post-state for the nominal steering (the only one when nothing vetoes)
     Cand cA, cB;
     memset(&cA, 0, sizeof cA);
@@ -410,236 +595,235 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
     if (live) cA = predict<KIND, SHIELDED>(v, v.act_steer, dt);
     cB = cA;
     double steerB = v.act_steer;
+    bool needB = false;
     if (SHIELDED) {
       // LC veto re-steers to the CURRENT lane (decentral_layer.py:501-506,739-744); identical to
       // the nominal command unless a lane change / lane hand-over is under way or the car crashed
-      if (shield_on && (v.tlane != v.lane || v.crashed)) {
+      needB = shield_on && (v.tlane != v.lane || v.crashed);
+      if (needB) {
         steerB = steering_control(v.x, v.y, v.h, v.v, v.lane);
         cB = predict<KIND, true>(v, steerB, dt);
       }
     }
-    double new_acc = v.act_acc, new_steer = v.act_steer;
-    bool use_B = false;
+    double new_acc = v.act_acc;
+    bool use_B = false, veto = false;
+    int new_flags = v.flags;
 
-    if (SHIELDED) {
-      if (__any(shield_on)) {
-        // ---------------- front-to-back sweep -------------------------------------------------
-        bool stepped = false;
+    if (SHIELDED && __any(shield_on)) {
+      // Road.step order: sorted by x descending, stable (road.py:286) -> rank; lower = steps earlier
+      int rank = 0;
+      for_partners<G>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        double px = dppx_d<m>(v.x);
+        bool pp = dppx_i<m>((int)live) != 0;
+        rank += (pp && (px > v.x || (px == v.x && (a ^ m) < a))) ? 1 : 0;
+      });
+      bool serial = (c.debug_flags & 1) != 0;
+      ShieldOut so;
+      memset(&so, 0, sizeof so);
+      if (!serial) {
+        // ------------- parallel form of the front-to-back sweep --------------------------------
+        // When vehicle i runs its shield, vehicle j is in its committed post-state if it steps
+        // earlier (rank_j < rank_i), else in its pre-step state.  Post-states are the predicted
+        // candidates (A, or B where j's own shield vetoes), so every lane can classify its
+        // neighbours at once; what remains serial is (1) MASS: a follower needs its leader's
+        // DECIDED acceleration -> fixed point over the leader chain, (2) a veto changes what
+        // later vehicles see -> outer fixed point.  Both iterate to the unique sequential answer
+        // (induction on rank: the rank-r vehicle is final after r+1 rounds / passes).
+        bool irregular = false;
+        for (int pass = 0; pass <= st.N; pass++) {
+          const Cand &mine = use_B ? cB : cA;
+          // what I show to a partner: post-state if I step before it, else pre-state
+          double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
+          int j_ol = -1, j_oa = -1, j_oar = -1;
+          Neigh nb;
+          memset(&nb, 0, sizeof nb);
+          double keys[G];
+          keys[0] = INFINITY;
+          bool ol_dyn = false, oa_dyn = false, oar_stepped = false;
+          for_partners<G>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const int p = a ^ m;
+            const int p_rank = dppx_i<m>(live ? rank : 99);
+            const bool i_first = live && rank < p_rank;  // I step before this partner
+            // message: my state as that partner sees it
+            const double sx_ = i_first ? mine.x : v.x, sy_ = i_first ? mine.y : v.y, sh_ = i_first ? mine.h : v.h;
+            const int spk = i_first ? (mine.lane | mine.nl << 3 | (int)mine.offL << 6 | (int)mine.offR << 7)
+                                    : (v.lane | nl_self << 3 | (int)offL << 6 | (int)offR << 7);
+            const double shx = i_first ? v.h1x : v.h2x, shvx = i_first ? v.h1vx : v.h2vx;  // my state_hist[-2] as seen then
+            const double sg = i_first ? mine.gvx : v.gvx;
+            const double sacc = v.safe_acc;   // my previous decision (read only if I have not stepped)
+            const double svx = v.v * cpsi;    // my current vx (rear-adjacent slot reads to_dict())
+            const double ox = dppx_d<m>(sx_), oy = dppx_d<m>(sy_), oh = dppx_d<m>(sh_);
+            const int opk = dppx_i<m>(spk | (int)live << 8);
+            const double ohx = dppx_d<m>(shx), ohvx = dppx_d<m>(shvx), og = dppx_d<m>(sg);
+            const double oacc = dppx_d<m>(sacc), ovx = dppx_d<m>(svx);
+            const bool o_first = !i_first && p_rank < 99;  // partner steps before me (ranks are distinct)
+            const Rel r = relate(v.x, v.y, v.lane, nl_self, ((opk >> 8) & 1) != 0, ox, oy, oh, opk & 7, (opk >> 3) & 7,
+                                 ((opk >> 6) & 1) != 0, ((opk >> 7) & 1) != 0);
+            keys[m] = r.key;
+            // running "first in sorted order" per class: smaller key, ties by creation index
+            if (r.cls == 1 && (r.key < k_ol || (r.key == k_ol && p < j_ol))) {
+              k_ol = r.key; j_ol = p; nb.ol_x = ohx; nb.ol_vx = ohvx; nb.ol_g = og; nb.ol_acc = oacc; ol_dyn = o_first;
+            }
+            if (r.cls == 2 && (r.key < k_oa || (r.key == k_oa && p < j_oa))) {
+              k_oa = r.key; j_oa = p; nb.oa_x = ohx; nb.oa_vx = ohvx; nb.oa_g = og; nb.oa_acc = oacc; oa_dyn = o_first;
+              nb.constrain_adj = r.cflag;
+            }
+            if (r.cls == 3 && (r.key < k_oar || (r.key == k_oar && p < j_oar))) {
+              k_oar = r.key; j_oar = p; nb.oar_x = ox; nb.oar_vx = ovx; oar_stepped = o_first;
+            }
+          });
+          // count = 5 of close_vehicles_to: a slot exists only if its vehicle is among the 5 nearest
+          {
+            int pos_ol = 0, pos_oa = 0, pos_oar = 0;
+#pragma unroll
+            for (int m = 1; m < G; m++) {
+              const int p = a ^ m;
+              pos_ol += (keys[m] < k_ol || (keys[m] == k_ol && p < j_ol)) ? 1 : 0;
+              pos_oa += (keys[m] < k_oa || (keys[m] == k_oa && p < j_oa)) ? 1 : 0;
+              pos_oar += (keys[m] < k_oar || (keys[m] == k_oar && p < j_oar)) ? 1 : 0;
+            }
+            nb.has_ol = j_ol >= 0 && pos_ol < 5;
+            nb.has_oa = j_oa >= 0 && pos_oa < 5;
+            nb.has_oar = j_oar >= 0 && pos_oar < 5;
+          }
+          nb.constrain_adj = MASS && nb.has_oa && nb.constrain_adj;
+          if (!nb.has_ol) { nb.ol_acc = 0; nb.ol_g = 0; ol_dyn = false; }  // defaults a_ol / gp["ol"] (:93-95)
+          if (!nb.has_oa) { nb.oa_acc = 0; nb.oa_g = 0; oa_dyn = false; }
+          if (!MASS) { nb.ol_acc = kCbfAccLo; nb.oa_acc = kCbfAccLo; ol_dyn = oa_dyn = false; }  // worst case :473
+          {
+            unsigned rep = obstacle_override<MASS>(nb, v.x, v.y);  // the obstacle's action is static
+            if (rep & 1u) ol_dyn = false;
+            if (rep & 2u) oa_dyn = false;
+          }
+          // a stepped vehicle seen as REAR-adjacent would need its post-step speed: only possible when
+          // a vehicle moves backwards in x; handled by the serial form below
+          irregular = irregular || (shield_on && nb.has_oar && oar_stepped);
+          // ---- MASS: fixed point over the decided accelerations (HSS: one evaluation) ----------
+          const int src_ol = gb + (j_ol < 0 ? 0 : j_ol), src_oa = gb + (j_oa < 0 ? 0 : j_oa);
+          double acc_cur = shield_on ? 0.0 : v.act_acc;  // vehicles without a shield keep their command
+          for (int round = 0; round <= st.N; round++) {
+            if (MASS) {
+              const double da = shfl_d(acc_cur, src_ol), db = shfl_d(acc_cur, src_oa);
+              if (ol_dyn) nb.ol_acc = da;
+              if (oa_dyn) nb.oa_acc = db;
+            }
+            so = shield_eval<MASS>(c, v, cpsi, offL, offR, nb);
+            const double acc_next = shield_on ? so.acc : v.act_acc;
+            const bool changed = __double_as_longlong(acc_next) != __double_as_longlong(acc_cur);
+            acc_cur = acc_next;
+            if (!MASS || !__any(changed)) break;
+          }
+          const bool want_B = shield_on && so.veto && needB;
+          const bool flip = want_B != use_B;
+          use_B = want_B;
+          if (!__any(flip)) break;
+        }
+        serial = __any(irregular);
+        if (!serial && shield_on) {
+          new_acc = so.acc; veto = so.veto; new_flags = so.flags; qt = so.qt;
+        }
+      }
+      if (serial) {
+        // ------------- literal front-to-back sweep (fallback / validation form) -----------------
+        use_B = false; veto = false; new_acc = v.act_acc; new_flags = v.flags;
+        // working copy of what the others see of me; committed stage by stage
+        double wx = v.x, wy = v.y, wh = v.h, wg = v.gvx, wacc = v.safe_acc, wvx = v.v * cpsi;
+        double whx = v.h2x, whvx = v.h2vx;
+        int wlane = v.lane, wnl = nl_self;
+        bool woffL = offL, woffR = offR;
         for (int r = 0; r < st.N; r++) {
           const unsigned sel = group_ballot<G>(shield_on && rank == r, gb);
           const bool has = sel != 0;
           const int ai = has ? (__ffs((int)sel) - 1) : 0;
           const int src = gb + ai;
-          // ego broadcast: position, lane, next lane
           const double ex = shfl_d(v.x, src), ey = shfl_d(v.y, src);
           const int epk = shfl_i(v.lane | (nl_self << 4), src);
-          const int elane = epk & 15, enl = epk >> 4;
-          // ---- relation of this lane's vehicle (current state) to the ego (decentral_layer.py:85-211)
-          const bool other = v.present && env_active && has && a != ai;
-          const double dx = v.x - ex, dy = v.y - ey;
-          const bool close = other && sqrt(dx * dx + dy * dy) < kPerception;
-          const double esx = lane_sx(elane);
-          const double ld = (v.x - esx) - (ex - esx);  // ego.lane_distance_to(veh)
-          const double key = close ? fabs(ld) : INFINITY;
-          int pos = 0;  // index in close_vehicles_to(...) (road.py:257-267), count = 5
-#pragma unroll
-          for (int m = 1; m < G; m++) {
-            double kp = shflx_d(key, m);
-            pos += (kp < key || (kp == key && (a ^ m) < a)) ? 1 : 0;
-          }
-          const bool in5 = close && pos < 5;
-          const int v_a = adj_lane(elane, enl, v.lane);
-          const int a_v = adj_lane(v.lane, nl_self, elane);
-          const bool appr = !(ld < 0) && fabs(dy) <= 3.5 && (dy < 0 ? v.h > 0.037 : v.h < -0.037);  // :46-57
-          const bool adj = !appr && (v_a != 0 || a_v != 0);
-          const bool same = (elane == v.lane) || (v.lane == enl);  // is_same_lane :15-20
-          const bool c_oar = in5 && adj && ld < 0;
-          const bool c_oa = in5 && adj && ld >= 0;
-          const bool c_ol = in5 && !adj && (same || appr) && ld > 0;
-          const bool use_left = (v_a == -1 || a_v == 1);  // :146-152 which front corner of veh
-          const unsigned cflag = (use_left ? offL : offR) ? 1u : 0u;
+          const Rel rl = relate(ex, ey, epk & 15, epk >> 4, live && has && a != ai, wx, wy, wh, wlane, wnl, woffL, woffR);
+          int pos = 0;
+          for_partners<G>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            double kp = dppx_d<m>(rl.key);
+            pos += (kp < rl.key || (kp == rl.key && (a ^ m) < a)) ? 1 : 0;
+          });
+          const bool in5 = rl.key < INFINITY && pos < 5;
           const unsigned none = 0x3FFu;
-          unsigned f_ol = c_ol ? ((unsigned)pos << 5 | (unsigned)a << 1) : none;
-          unsigned f_oa = c_oa ? ((unsigned)pos << 5 | (unsigned)a << 1 | cflag) : none;
-          unsigned f_oar = c_oar ? ((unsigned)pos << 5 | (unsigned)a << 1) : none;
+          unsigned f_ol = (in5 && rl.cls == 1) ? ((unsigned)pos << 5 | (unsigned)a << 1) : none;
+          unsigned f_oa = (in5 && rl.cls == 2) ? ((unsigned)pos << 5 | (unsigned)a << 1 | (rl.cflag ? 1u : 0u)) : none;
+          unsigned f_oar = (in5 && rl.cls == 3) ? ((unsigned)pos << 5 | (unsigned)a << 1) : none;
           unsigned w = f_ol | f_oa << 10 | f_oar << 20;
 #pragma unroll
           for (int m = 1; m < G; m <<= 1) {
-            unsigned o = (unsigned)shflx_i((int)w, m);
+            unsigned o = (unsigned)__shfl_xor((int)w, m, 64);
             unsigned m0 = min(w & 0x3FFu, o & 0x3FFu), m1 = min((w >> 10) & 0x3FFu, (o >> 10) & 0x3FFu),
                      m2 = min((w >> 20) & 0x3FFu, (o >> 20) & 0x3FFu);
             w = m0 | m1 << 10 | m2 << 20;
           }
           f_ol = w & 0x3FFu; f_oa = (w >> 10) & 0x3FFu; f_oar = (w >> 20) & 0x3FFu;
-          bool has_ol = f_ol != none, has_oa = f_oa != none;
-          const bool has_oar = f_oar != none;
-          const int s_ol = gb + (has_ol ? (int)((f_ol >> 1) & 15u) : 0);
-          const int s_oa = gb + (has_oa ? (int)((f_oa >> 1) & 15u) : 0);
-          const int s_oar = gb + (has_oar ? (int)((f_oar >> 1) & 15u) : 0);
-          // s_ol / s_oa = veh.state_hist[-2] (x, vx); MASS adds veh.safe_action, veh.fg_params["g"]
-          double ol_x = shfl_d(v.h2x, s_ol), ol_vx = shfl_d(v.h2vx, s_ol);
-          double oa_x = shfl_d(v.h2x, s_oa), oa_vx = shfl_d(v.h2vx, s_oa);
-          double ol_acc = 0, ol_g = 0, oa_acc = 0, oa_g = 0;
+          Neigh nb;
+          nb.has_ol = f_ol != none; nb.has_oa = f_oa != none; nb.has_oar = f_oar != none;
+          const int s_ol = gb + (nb.has_ol ? (int)((f_ol >> 1) & 15u) : 0);
+          const int s_oa = gb + (nb.has_oa ? (int)((f_oa >> 1) & 15u) : 0);
+          const int s_oar = gb + (nb.has_oar ? (int)((f_oar >> 1) & 15u) : 0);
+          nb.ol_x = shfl_d(whx, s_ol); nb.ol_vx = shfl_d(whvx, s_ol);
+          nb.oa_x = shfl_d(whx, s_oa); nb.oa_vx = shfl_d(whvx, s_oa);
+          nb.ol_acc = nb.ol_g = nb.oa_acc = nb.oa_g = 0;
           if (MASS) {
-            ol_acc = shfl_d(v.safe_acc, s_ol); ol_g = shfl_d(v.gvx, s_ol);
-            oa_acc = shfl_d(v.safe_acc, s_oa); oa_g = shfl_d(v.gvx, s_oa);
+            nb.ol_acc = shfl_d(wacc, s_ol); nb.ol_g = shfl_d(wg, s_ol);
+            nb.oa_acc = shfl_d(wacc, s_oa); nb.oa_g = shfl_d(wg, s_oa);
           }
-          // s_oar = veh.to_dict(): current x and vx = speed*mmm_cos(heading)
-          const double oar_x = shfl_d(v.x, s_oar), oar_vx = shfl_d(v.v * cpsi, s_oar);
-          bool constrain_adj = MASS && has_oa && (f_oa & 1u);
-          if (!has_ol) { ol_acc = 0; ol_g = 0; }  // defaults a_ol / gp["ol"] (:93-95)
-          if (!has_oa) { oa_acc = 0; oa_g = 0; }
-          if (!MASS) { ol_acc = kCbfAccLo; oa_acc = kCbfAccLo; }  // worst-case leader braking :473
-          // ---- from here on every lane acts as "ego" on its own registers; only lane ai commits
-          // obstacle at (420, 4) as leader / adjacent (:213-246)
-          if (!(v.x > kObstX)) {
-            const double ady = fabs(kObstY - v.y);
-            if ((!has_ol || kObstX <= ol_x) && ady <= 2) {
-              has_ol = true; ol_x = kObstX; ol_vx = 0.0;
-              if (MASS) { ol_acc = 0; ol_g = 0; }
-            }
-            if ((!has_oa || kObstX <= oa_x) && (2 < ady && ady <= 4)) {
-              has_oa = true; oa_x = kObstX; oa_vx = 0.0;
-              if (MASS) { oa_acc = 0; oa_g = 0; constrain_adj = false; }
-            }
-          }
-          // safe_action_hss / safe_action_mass (:290-518 / :521-764), scalar form of the 8-vectors
-          double v_min = v.v + kLcMinAcc * dt;
-          if (MASS) v_min = v_min > 0 ? v_min : 0;  // :798
-          const double v_max = v.v + kLcMaxAcc * dt;
-          double evx = v.v * cpsi;
-          evx = evx > 1 ? evx : 1;  // :307-309
-          const double x_e = v.x;
-          const double x_ol = has_ol ? ol_x : x_e + kPerception + 1;
-          const double x_oa = has_oa ? oa_x : x_e + kPerception + 1;
-          const double x_oar = has_oar ? oar_x : x_e - kPerception - 1;
-          const double g0 = v.gvx * dt;
-          const double g2 = MASS ? ol_g * dt : 1 * dt;
-          const double g4 = MASS ? oa_g * dt : 1 * dt;
-          const double g6 = 1 * dt;
-          double sv_oar = has_oar ? oar_vx : 0;
-          sv_oar = sv_oar + kCbfAccHi * dt;
-          sv_oar = sv_oar > 1 ? sv_oar : 1;
-          const double buffer = (kCbfAccHi + 0.1) * dt * c.tau;
-          const double sd0 = evx * c.tau + kVehLength + buffer;
-          const double sd2 = sv_oar * c.tau + kVehLength + buffer;
-          // simplified_control (:60-77): only the speed components enter the CBF rows
-          double u0 = evx + v.act_acc * dt; u0 = u0 > 0 ? u0 : 0;
-          double u2 = 0, u4 = 0, u6 = 0;
-          if (has_ol) { u2 = ol_vx + ol_acc * dt; u2 = u2 > 0 ? u2 : 0; }
-          if (has_oa) { u4 = oa_vx + oa_acc * dt; u4 = u4 > 0 ? u4 : 0; }
-          if (has_oar) { u6 = oar_vx + kCbfAccHi * dt; u6 = u6 > 0 ? u6 : 0; }
-          // cbf.py:262-322, :374-422
-          const double eta = c.eta;
-          const double q_lon = -kVehLength - sd0;
-          double q_lona = -kVehLength - sd0;
-          const double q_lonr = -kVehLength - sd2;
-          if (MASS && constrain_adj) q_lona = -kVehLength - sd0 - kAdjBuffer;
-          const double px_lon = x_ol - x_e, px_lona = x_oa - x_e, px_lonr = x_e - x_oar;
-          const double h0 = px_lon + (eta - 1) * px_lon + eta * q_lon + (-(g0 * u0) + g2 * u2);
-          const double h1 = v_max - u0;
-          const double h2 = -v_min + u0;
-          double h3 = __builtin_nan(""), hc = h0;
-          if (MASS && constrain_adj) {
-            h3 = px_lona + (eta - 1) * px_lona + eta * q_lona + (-(g0 * u0) + g4 * u4);
-            hc = h3 < h0 ? h3 : h0;
-          }
-          // exact KKT point of min 1/2(d^2 + e^2 + 1e18 s^2) s.t. a d - s <= hc, lo <= d <= hi
-          double d;
-          if (g0 > 0) d = fmin(0.0, hc / g0);
-          else if (g0 < 0) d = fmax(0.0, hc / g0);
-          else d = 0.0;
-          d = fmin(fmax(d, -h2), h1);
-          double us0 = u0 + d;
-          // is_lc_allowed (cbf.py:324-339) with u = [u_safe0, steer, u2.., u6..]
-          const double hls_lona = px_lona + q_lona;
-          const double hlds_lona = px_lona + ((-g0) * us0 + g4 * u4) + q_lona;
-          const double hls_lonr = px_lonr + q_lonr;
-          const double hlds_lonr = px_lonr + (g0 * us0 + (-g6) * u6) + q_lonr;
-          const bool lc_allowed = ((hls_lona >= 0) && (hlds_lona + (eta - 1) * hls_lona) >= 0) &&
-                                  ((hls_lonr >= 0) && (hlds_lonr + (eta - 1) * hls_lonr) >= 0);
-          bool veto;
-          int fl = v.flags & MM_FLAG_COLLABORATE_ADJ;
-          if (constrain_adj) fl |= MM_FLAG_IS_COLLABORATING;
-          if (!MASS) {
-            veto = !lc_allowed;
-          } else {
-            const bool can_abort_lc = !offL && !offR;  // :728-736 on the pre-step pose
-            veto = can_abort_lc && !lc_allowed;
-            if (!veto && (v.hl == 2 || v.hl == 0) && v.v < kStoppingSpeed) us0 = u0;  // :746-750
-            if ((hlds_lona + (eta - 1) * hls_lona) >= -1e-6) fl |= MM_FLAG_COLLABORATE_ADJ;  // cbf.py:424-430
-            else fl &= ~MM_FLAG_COLLABORATE_ADJ;
-          }
-          if (!veto) fl |= MM_FLAG_IS_LC_SAFE;
+          nb.oar_x = shfl_d(wx, s_oar); nb.oar_vx = shfl_d(wvx, s_oar);
+          nb.constrain_adj = MASS && nb.has_oa && (f_oa & 1u);
+          if (!nb.has_ol) { nb.ol_acc = 0; nb.ol_g = 0; }
+          if (!nb.has_oa) { nb.oa_acc = 0; nb.oa_g = 0; }
+          if (!MASS) { nb.ol_acc = kCbfAccLo; nb.oa_acc = kCbfAccLo; }
+          obstacle_override<MASS>(nb, v.x, v.y);
+          const ShieldOut s1 = shield_eval<MASS>(c, v, cpsi, offL, offR, nb);
           if (has && a == ai && shield_on) {
-            new_acc = (us0 - evx) / dt;  // derived_acceleration :80-82
-            use_B = veto;
-            new_steer = veto ? steerB : v.act_steer;
-            if (veto) v.tlane = v.lane;
-            v.flags = fl;
-            qt.rows = (MASS && constrain_adj) ? 4 : 3; qt.a = g0; qt.h0 = h0; qt.h1 = h1; qt.h2 = h2;
-            qt.h3 = h3; qt.d = d;
-            qt.margin = fmin(fmin(hls_lona, hlds_lona + (eta - 1) * hls_lona),
-                             fmin(hls_lonr, hlds_lonr + (eta - 1) * hls_lonr));
-            // commit Vehicle.step now: followers must see this vehicle's post-step state
+            new_acc = s1.acc; veto = s1.veto; new_flags = s1.flags; qt = s1.qt;
+            use_B = veto && needB;
             const Cand &cc = use_B ? cB : cA;
             double nv = v.v + new_acc * dt;
             nv = nv > 0 ? nv : 0;
-            v.safe_steer = new_steer; v.safe_acc = new_acc;
-            v.x = cc.x; v.y = cc.y; v.h = cc.h; v.v = nv; v.gvx = cc.gvx; v.lane = cc.lane;
-            cpsi = cc.cpsi; offL = cc.offL; offR = cc.offR;
-            nl_self = next_lane(v.lane, v.x, v.y);
-            v.h2x = v.h1x; v.h2h = v.h1h; v.h2vx = v.h1vx; v.h2v = v.h1v;  // log_step :187-201
-            v.h1x = v.x; v.h1h = v.h; v.h1vx = v.v * cpsi; v.h1v = v.v;
-            stepped = true;
+            // publish my post-step view (Vehicle.step committed) for the later stages
+            wx = cc.x; wy = cc.y; wh = cc.h; wg = cc.gvx; wacc = new_acc; wvx = nv * cc.cpsi;
+            whx = v.h1x; whvx = v.h1vx; wlane = cc.lane; wnl = cc.nl; woffL = cc.offL; woffR = cc.offR;
           }
         }
-        // vehicles whose shield is still gated (first two sub-steps of an episode) step unshielded
-        if (live && !stepped) {
-          double nv = v.v + v.act_acc * dt;
-          nv = nv > 0 ? nv : 0;
-          v.safe_steer = v.act_steer; v.safe_acc = v.act_acc;
-          v.x = cA.x; v.y = cA.y; v.h = cA.h; v.v = nv; v.gvx = cA.gvx; v.lane = cA.lane;
-          cpsi = cA.cpsi; offL = cA.offL; offR = cA.offR;
-          nl_self = next_lane(v.lane, v.x, v.y);
-          v.h2x = v.h1x; v.h2h = v.h1h; v.h2vx = v.h1vx; v.h2v = v.h1v;
-          v.h1x = v.x; v.h1h = v.h; v.h1vx = v.v * cpsi; v.h1v = v.v;
-          if (v.hist_len < 2) v.hist_len++;
-        }
-      } else if (live) {
-        double nv = v.v + v.act_acc * dt;
-        nv = nv > 0 ? nv : 0;
-        v.safe_steer = v.act_steer; v.safe_acc = v.act_acc;
-        v.x = cA.x; v.y = cA.y; v.h = cA.h; v.v = nv; v.gvx = cA.gvx; v.lane = cA.lane;
-        cpsi = cA.cpsi; offL = cA.offL; offR = cA.offR;
-        nl_self = next_lane(v.lane, v.x, v.y);
-        v.h2x = v.h1x; v.h2h = v.h1h; v.h2vx = v.h1vx; v.h2v = v.h1v;
-        v.h1x = v.x; v.h1h = v.h; v.h1vx = v.v * cpsi; v.h1v = v.v;
-        if (v.hist_len < 2) v.hist_len++;
       }
-    } else if (live) {
-      // unshielded Vehicle.step / MDPLCVehicle.step: every vehicle integrates independently
-      double nv = v.v + v.act_acc * dt;
-      nv = nv > 0 ? nv : 0;
-      v.x = cA.x; v.y = cA.y; v.h = cA.h; v.v = nv; v.lane = cA.lane;
+    }
+    // ---------------- commit Vehicle.step / MDPLCVehicle.step for every vehicle -------------------
+    if (live) {
+      const Cand &cc = use_B ? cB : cA;
+      const double acc = (SHIELDED && shield_on) ? new_acc : v.act_acc;
+      double nv = v.v + acc * dt;
+      nv = nv > 0 ? nv : 0;  // max(0, speed)
+      if (SHIELDED && shield_on) {
+        if (veto) v.tlane = v.lane;
+        v.flags = new_flags;
+      }
+      v.x = cc.x; v.y = cc.y; v.h = cc.h; v.v = nv; v.lane = cc.lane;
       if (LC) {
-        v.safe_steer = v.act_steer; v.safe_acc = v.act_acc; v.gvx = cA.gvx;
-        v.h2x = v.h1x; v.h2h = v.h1h; v.h2vx = v.h1vx; v.h2v = v.h1v;
-        v.h1x = v.x; v.h1h = v.h; v.h1vx = v.v * cA.cpsi; v.h1v = v.v;
+        v.safe_steer = (SHIELDED && shield_on && veto) ? steerB : v.act_steer;
+        v.safe_acc = acc; v.gvx = cc.gvx;
+        v.h2x = v.h1x; v.h2h = v.h1h; v.h2vx = v.h1vx; v.h2v = v.h1v;  // log_step :187-201
+        v.h1x = v.x; v.h1h = v.h; v.h1vx = v.v * cc.cpsi; v.h1v = v.v;
         if (v.hist_len < 2) v.hist_len++;
       }
+      if (SHIELDED) { cpsi = cc.cpsi; offL = cc.offL; offR = cc.offR; nl_self = cc.nl; }
     }
 
     // ---------------- collisions (road.py:288-292, kinematics.py:175-209) ----------------------
     unsigned hits = 0;
-#pragma unroll
-    for (int m = 1; m < G; m++) {
-      double px = shflx_d(v.x, m), py = shflx_d(v.y, m), ph = shflx_d(v.h, m);
-      bool pp = shflx_i((int)(v.present && env_active), m) != 0;
+    for_partners<G>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      double px = dppx_d<m>(v.x), py = dppx_d<m>(v.y), ph = dppx_d<m>(v.h);
+      bool pp = dppx_i<m>((int)live) != 0;
       double dx = px - v.x, dy = py - v.y;
       if (live && pp && !(sqrt(dx * dx + dy * dy) > kVehLength))
         if (rects_intersect(v.x, v.y, v.h, px, py, kVehLength, kVehWidth, ph)) hits |= 1u << (a ^ m);
-    }
+    });
     bool obst_hit = false;
     if (live) {
       double dx = kObstX - v.x, dy = kObstY - v.y;
@@ -681,7 +865,6 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
     // _is_terminal (merge_env_v1.py:168-172) breaks the sub-step loop (abstract.py:530)
     const bool term = group_ballot<G>(v.present && (v.crashed || v.x < 0), gb) != 0 || steps >= c.T;
     if (term) env_active = false;
-    (void)new_steer;
   }
 
   // ---------------- rewards / info (merge_env_v1.py:59-166, abstract.py:469-498) -----------------
@@ -712,11 +895,11 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
   double hd = 60;  // _compute_headway_distance abstract.py:620-635
   double of_s = 0, or_s = 0, sf_s = 0, sr_s = 0;
   int of_i = -1, or_i = -1, sf_i = -1, sr_i = -1;  // own/side chain front & rear
-#pragma unroll
-  for (int m = 1; m < G; m++) {
+  for_partners<G>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
     const int p = a ^ m;
-    double px = shflx_d(v.x, m);
-    int pk = shflx_i(v.present ? v.lane : 15, m);
+    double px = dppx_d<m>(v.x);
+    int pk = dppx_i<m>(v.present ? v.lane : 15);
     bool pp = pk != 15;
     if (pp && pk == v.lane && px > v.x) { double dd = px - v.x; if (dd < hd) hd = dd; }
     if (pp && v.lane != MM_LANE_BC1 && pk == nl && px > v.x) { double dd = px - v.x; if (dd < hd) hd = dd; }
@@ -726,7 +909,7 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
     if (in_own && px < v.x && (or_i < 0 || px > or_s || (px == or_s && p < or_i))) { or_s = px; or_i = p; }
     if (in_side && v.x <= px && (sf_i < 0 || px < sf_s || (px == sf_s && p > sf_i))) { sf_s = px; sf_i = p; }
     if (in_side && px < v.x && (sr_i < 0 || px > sr_s || (px == sr_s && p < sr_i))) { sr_s = px; sr_i = p; }
-  }
+  });
   // _agent_reward merge_env_v1.py:64-89
   double local = 0;
   if (v.present) {
@@ -827,15 +1010,15 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
     st.I[MM_E_STEPS * st.E + e] = steps; st.I[MM_E_TIME * st.E + e] = time;
     st.I[MM_E_N_MERGE * st.E + e] = n_merge; st.I[MM_E_EPISODE * st.E + e] = episode;
   }
-  observe<G, KIND, OBS_T>(c, v, a, gb, i, valid, (OBS_T *)out.obs, out.action_mask);
+  observe<G, KIND>(c, v, a, gb, i, valid, out.obs, out.action_mask);
 }
 
 // reset / init / observe --------------------------------------------------------------------------
 // mode 0: device-RNG spawn (mm_reset), 1: finish a host-provided spawn (mm_init_from_kinematics),
 // 2: observe only (mm_observe)
-template <int G, int KIND, typename OBS_T>
+template <int G, int KIND>
 __global__ __launch_bounds__(256) void reset_kernel(DevCfg c, DevState st, int mode, const uint8_t *env_mask,
-                                                    const uint64_t *seeds_in, OBS_T *obs, uint8_t *avail) {
+                                                    const uint64_t *seeds_in, void *obs, uint8_t *avail) {
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long e = gtid / G;
   const int a = (int)(gtid % G);
@@ -863,10 +1046,8 @@ __global__ __launch_bounds__(256) void reset_kernel(DevCfg c, DevState st, int m
       st.I[MM_E_STEPS * st.E + e] = steps; st.I[MM_E_TIME * st.E + e] = time;
       st.I[MM_E_N_MERGE * st.E + e] = n_merge; st.I[MM_E_EPISODE * st.E + e] = episode;
     }
-  } else if (e < st.E && mode == 0 && env_mask) {
-    (void)0;  // untouched env: only re-observed below
   }
-  observe<G, KIND, OBS_T>(c, v, a, gb, i, valid, obs, avail);
+  observe<G, KIND>(c, v, a, gb, i, valid, obs, avail);
 }
 
 // stand-alone batched shield QP (cbf.py:110-161): exact KKT point, one thread per QP
@@ -971,6 +1152,7 @@ static DevCfg dev_cfg(const MMHandle h) {
   d.env_kind = c.env_kind; d.shield = c.env_kind == MM_ENV_V1 ? c.shield : MM_SHIELD_NONE;
   d.nsub = c.simulation_frequency / c.policy_frequency; d.T = c.duration * c.policy_frequency;
   d.action_masking = c.action_masking; d.auto_reset = c.auto_reset; d.obs_f64 = c.obs_f64; d.N = h->N;
+  d.debug_flags = c.debug_flags;
   d.dt = 1.0 / c.simulation_frequency;
   d.collision_reward = c.collision_reward; d.high_speed_reward = c.high_speed_reward;
   d.headway_cost = c.headway_cost; d.headway_time = c.headway_time; d.merging_lane_cost = c.merging_lane_cost;
@@ -986,22 +1168,19 @@ static DevState dev_state(const MMHandle h) {
 }
 static int group_size(int N) { return N <= 2 ? 2 : (N <= 4 ? 4 : (N <= 8 ? 8 : 16)); }
 
-template <int G, int KIND, typename OBS_T>
+template <int G, int KIND>
 static void launch_reset_t(MMHandle h, int mode, const uint8_t *mask, const uint64_t *seeds, void *obs,
                            uint8_t *avail, hipStream_t s) {
   const long long threads = (long long)h->E * G;
   const unsigned grid = (unsigned)((threads + 255) / 256);
-  hipLaunchKernelGGL((reset_kernel<G, KIND, OBS_T>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), mode,
-                     mask, seeds, (OBS_T *)obs, avail);
+  hipLaunchKernelGGL((reset_kernel<G, KIND>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), mode, mask,
+                     seeds, obs, avail);
 }
 template <int G>
 static void launch_reset_g(MMHandle h, int mode, const uint8_t *mask, const uint64_t *seeds, void *obs,
                            uint8_t *avail, hipStream_t s) {
-  const bool v1 = h->cfg.env_kind == MM_ENV_V1, f64 = h->cfg.obs_f64 != 0;
-  if (v1 && f64) launch_reset_t<G, MM_ENV_V1, double>(h, mode, mask, seeds, obs, avail, s);
-  else if (v1) launch_reset_t<G, MM_ENV_V1, float>(h, mode, mask, seeds, obs, avail, s);
-  else if (f64) launch_reset_t<G, MM_ENV_V0, double>(h, mode, mask, seeds, obs, avail, s);
-  else launch_reset_t<G, MM_ENV_V0, float>(h, mode, mask, seeds, obs, avail, s);
+  if (h->cfg.env_kind == MM_ENV_V1) launch_reset_t<G, MM_ENV_V1>(h, mode, mask, seeds, obs, avail, s);
+  else launch_reset_t<G, MM_ENV_V0>(h, mode, mask, seeds, obs, avail, s);
 }
 static int launch_reset(MMHandle h, int mode, const uint8_t *mask, const uint64_t *seeds, void *obs,
                         uint8_t *avail, MMStream stream) {
@@ -1030,33 +1209,20 @@ extern "C" int32_t mm_observe(MMHandle h, void *obs, uint8_t *avail, MMStream st
   return launch_reset(h, 2, nullptr, nullptr, obs, avail, stream);
 }
 
-template <int G, int KIND, int SHIELD, typename OBS_T>
+template <int G, int KIND, int SHIELD>
 static void launch_step_t(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   const long long threads = (long long)h->E * G;
   const unsigned grid = (unsigned)((threads + 255) / 256);
-  hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, OBS_T>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h),
-                     actions, *out, h->metrics);
+  hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), actions,
+                     *out, h->metrics);
 }
 template <int G>
 static void launch_step_g(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
-  const bool f64 = h->cfg.obs_f64 != 0;
-  if (h->cfg.env_kind == MM_ENV_V0) {
-    if (f64) launch_step_t<G, MM_ENV_V0, MM_SHIELD_NONE, double>(h, actions, out, s);
-    else launch_step_t<G, MM_ENV_V0, MM_SHIELD_NONE, float>(h, actions, out, s);
-    return;
-  }
+  if (h->cfg.env_kind == MM_ENV_V0) { launch_step_t<G, MM_ENV_V0, MM_SHIELD_NONE>(h, actions, out, s); return; }
   switch (h->cfg.shield) {
-    case MM_SHIELD_HSS:
-      if (f64) launch_step_t<G, MM_ENV_V1, MM_SHIELD_HSS, double>(h, actions, out, s);
-      else launch_step_t<G, MM_ENV_V1, MM_SHIELD_HSS, float>(h, actions, out, s);
-      break;
-    case MM_SHIELD_MASS:
-      if (f64) launch_step_t<G, MM_ENV_V1, MM_SHIELD_MASS, double>(h, actions, out, s);
-      else launch_step_t<G, MM_ENV_V1, MM_SHIELD_MASS, float>(h, actions, out, s);
-      break;
-    default:
-      if (f64) launch_step_t<G, MM_ENV_V1, MM_SHIELD_NONE, double>(h, actions, out, s);
-      else launch_step_t<G, MM_ENV_V1, MM_SHIELD_NONE, float>(h, actions, out, s);
+    case MM_SHIELD_HSS: launch_step_t<G, MM_ENV_V1, MM_SHIELD_HSS>(h, actions, out, s); break;
+    case MM_SHIELD_MASS: launch_step_t<G, MM_ENV_V1, MM_SHIELD_MASS>(h, actions, out, s); break;
+    default: launch_step_t<G, MM_ENV_V1, MM_SHIELD_NONE>(h, actions, out, s);
   }
 }
 

@@ -30,7 +30,7 @@ class BatchedMergeEnv(object):
 
     def __init__(self, clib, E, N, env_id="merge-multi-agent-v1", config=None, device="cpu",
                  cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0, first_env=0,
-                 trace=False):
+                 trace=False, debug_flags=0):
         self.clib, self.E, self.N = clib, int(E), int(N)
         self.env_id = env_id
         self.device = torch.device(device)
@@ -39,6 +39,7 @@ class BatchedMergeEnv(object):
             self.config.update(config)
         self.cbf_eta, self.cbf_tau = cbf_eta, cbf_tau
         self.auto_reset, self.obs_f64, self.seed = auto_reset, obs_f64, seed
+        self.debug_flags = debug_flags
         self.n_f = 6 if env_id == "merge-multi-agent-v1" else 5
         self.n_s = 5 * self.n_f  # merge_env_v1.py:28 / :413
         self._cfg = self._make_cfg()
@@ -85,7 +86,8 @@ class BatchedMergeEnv(object):
     # -- configuration ------------------------------------------------------------------
     def _make_cfg(self):
         return abi.make_config(self.env_id, self.config, cbf_eta=self.cbf_eta, cbf_tau=self.cbf_tau,
-                               auto_reset=self.auto_reset, obs_f64=self.obs_f64, seed=self.seed)
+                               auto_reset=self.auto_reset, obs_f64=self.obs_f64, seed=self.seed,
+                               debug_flags=self.debug_flags)
 
     def configure(self, config=None, **kw):
         """env.config[k] = v after construction (run_mappo.py:145-171); CBFType globals via kw."""

@@ -99,6 +99,28 @@ def test_random_rollout_vs_oracle(env_id, safety, N, E, steps, eta, tau):
     print("bit-exact over %d steps x %d envs x %d agents" % (steps, E, N))
 
 
+@pytest.mark.parametrize("safety,N", [("cbf-cav", 8), ("cbf-avs_cint", 4), ("cbf-cav", 11)])
+def test_parallel_sweep_equals_literal_serial_sweep(safety, N):
+    """The parallel fixed-point form of the shield sweep vs the literal front-to-back sweep
+    (debug_flags bit0), LC-heavy action tape: identical bits everywhere."""
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5},
+              cbf_eta=0.03125, cbf_tau=0.5, seed=4242, auto_reset=True, trace=True)
+    E = 2048
+    fast, slow = _gpu_env(E, N, **kw), _gpu_env(E, N, debug_flags=1, **kw)
+    fast.reset()
+    slow.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(11)
+    p = torch.tensor([0.3, 0.2, 0.3, 0.1, 0.1], device="cuda:0")
+    for t in range(110):
+        a = torch.multinomial(p, E * N, True, generator=g).view(E, N).int()
+        fast.step(a)
+        slow.step(a)
+        assert torch.equal(fast.u8, slow.u8), t
+        assert torch.equal(fast.f64.nan_to_num(), slow.f64.nan_to_num()), t
+        assert torch.equal(fast.trace.nan_to_num(), slow.trace.nan_to_num()), t
+        assert torch.equal(fast.obs, slow.obs) and torch.equal(fast.out["reward"], slow.out["reward"]), t
+
+
 def test_float32_obs_matches_float64():
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
               cbf_eta=0.03125, cbf_tau=0.5, seed=7)
