@@ -64,8 +64,8 @@ def main():
     ap.add_argument("--env-id", default="merge-multi-agent-v1")
     ap.add_argument("--obs-f64", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-envs", type=int, default=16384)
-    ap.add_argument("--cpu-steps", type=int, default=200)
+    ap.add_argument("--cpu-envs", type=int, default=32768)
+    ap.add_argument("--cpu-steps", type=int, default=400)
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
 

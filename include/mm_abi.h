@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 1
+#define MM_ABI_VERSION 2
 #define MM_MAX_AGENTS 16 /* vehicles per env (reference draws 2..11, merge_env_v1.py:180-211) */
 #define MM_N_ACTIONS 5   /* DiscreteMetaAction.ACTIONS_ALL, envs/common/action.py:141-147 */
 #define MM_OBS_ROWS 5    /* KinematicObservation vehicles_count, envs/common/observation.py:132 */
@@ -63,14 +63,10 @@ enum {
   MM_F_SAFE_STEER,   /* MDPLCVehicle.safe_action["steering"]     safe_controller.py:122 */
   MM_F_SAFE_ACC,     /* MDPLCVehicle.safe_action["acceleration"]                     */
   MM_F_G_VX,         /* MDPLCVehicle.fg_params["g"]["vx"]        safe_controller.py:167 */
-  MM_F_H1_X,         /* state_hist[-1]: x, heading, vx, speed    safe_controller.py:187-201 */
-  MM_F_H1_HEADING,
-  MM_F_H1_VX,
-  MM_F_H1_SPEED,
-  MM_F_H2_X,         /* state_hist[-2] (read by the shield, decentral_layer.py:126,202) */
-  MM_F_H2_HEADING,
-  MM_F_H2_VX,
-  MM_F_H2_SPEED,
+  MM_F_H1_X,         /* state_hist[-1]["x"], ["vx"]              safe_controller.py:187-201 */
+  MM_F_H1_VX,        /*   (the shield reads only x and vx of a history record: the heading /   */
+  MM_F_H2_X,         /*    speed entries feed dpsi terms that no CBF row uses, cbf.py:206-257)  */
+  MM_F_H2_VX,        /* state_hist[-2] (decentral_layer.py:126,175,202)                        */
   MM_F_COUNT
 };
 

@@ -7,14 +7,14 @@ shared object is loaded is decided by the caller, never silently.
 import ctypes as C
 import os
 
-MM_ABI_VERSION = 1
+MM_ABI_VERSION = 2
 MM_MAX_AGENTS = 16
 ENV_V0, ENV_V1 = 0, 1
 SHIELD_NONE, SHIELD_HSS, SHIELD_MASS = 0, 1, 2
 
 # plane indices (keep in sync with include/mm_abi.h; checked by tests/test_abi.py)
 F_PLANES = ["X", "Y", "HEADING", "SPEED", "TARGET_SPEED", "SAFE_STEER", "SAFE_ACC", "G_VX",
-            "H1_X", "H1_HEADING", "H1_VX", "H1_SPEED", "H2_X", "H2_HEADING", "H2_VX", "H2_SPEED"]
+            "H1_X", "H1_VX", "H2_X", "H2_VX"]
 B_PLANES = ["LANE", "TARGET_LANE", "SPEED_INDEX", "CRASHED", "HL_ACTION", "FLAGS", "HIST_LEN", "KIND"]
 E_PLANES = ["STEPS", "TIME", "N_MERGE", "EPISODE"]
 T_PLANES = ["X", "Y", "HEADING", "SPEED", "ACT_STEER", "ACT_ACC", "SAFE_STEER", "SAFE_ACC", "LANE",

@@ -44,7 +44,7 @@ struct DevState {
 struct Veh {
   double x, y, h, v, tspeed;
   double act_steer, act_acc, safe_steer, safe_acc, gvx;
-  double h1x, h1h, h1vx, h1v, h2x, h2h, h2vx, h2v;
+  double h1x, h1vx, h2x, h2vx;  // x / vx of state_hist[-1], [-2]
   int lane, tlane, sidx, crashed, hl, flags, hist_len;
   bool present;
 };
@@ -128,10 +128,8 @@ MM_DEV void load_veh(const DevState &st, long long i, bool valid, Veh &v) {
   v.v = st.F[MM_F_SPEED * A + i]; v.tspeed = st.F[MM_F_TARGET_SPEED * A + i];
   v.safe_steer = st.F[MM_F_SAFE_STEER * A + i]; v.safe_acc = st.F[MM_F_SAFE_ACC * A + i];
   v.gvx = st.F[MM_F_G_VX * A + i];
-  v.h1x = st.F[MM_F_H1_X * A + i]; v.h1h = st.F[MM_F_H1_HEADING * A + i];
-  v.h1vx = st.F[MM_F_H1_VX * A + i]; v.h1v = st.F[MM_F_H1_SPEED * A + i];
-  v.h2x = st.F[MM_F_H2_X * A + i]; v.h2h = st.F[MM_F_H2_HEADING * A + i];
-  v.h2vx = st.F[MM_F_H2_VX * A + i]; v.h2v = st.F[MM_F_H2_SPEED * A + i];
+  v.h1x = st.F[MM_F_H1_X * A + i]; v.h1vx = st.F[MM_F_H1_VX * A + i];
+  v.h2x = st.F[MM_F_H2_X * A + i]; v.h2vx = st.F[MM_F_H2_VX * A + i];
   v.lane = st.B[MM_B_LANE * A + i]; v.tlane = st.B[MM_B_TARGET_LANE * A + i];
   v.sidx = st.B[MM_B_SPEED_INDEX * A + i]; v.crashed = st.B[MM_B_CRASHED * A + i];
   v.hl = st.B[MM_B_HL_ACTION * A + i]; v.flags = st.B[MM_B_FLAGS * A + i];
@@ -143,10 +141,8 @@ MM_DEV void store_veh(const DevState &st, long long i, const Veh &v) {
   st.F[MM_F_SPEED * A + i] = v.v; st.F[MM_F_TARGET_SPEED * A + i] = v.tspeed;
   st.F[MM_F_SAFE_STEER * A + i] = v.safe_steer; st.F[MM_F_SAFE_ACC * A + i] = v.safe_acc;
   st.F[MM_F_G_VX * A + i] = v.gvx;
-  st.F[MM_F_H1_X * A + i] = v.h1x; st.F[MM_F_H1_HEADING * A + i] = v.h1h;
-  st.F[MM_F_H1_VX * A + i] = v.h1vx; st.F[MM_F_H1_SPEED * A + i] = v.h1v;
-  st.F[MM_F_H2_X * A + i] = v.h2x; st.F[MM_F_H2_HEADING * A + i] = v.h2h;
-  st.F[MM_F_H2_VX * A + i] = v.h2vx; st.F[MM_F_H2_SPEED * A + i] = v.h2v;
+  st.F[MM_F_H1_X * A + i] = v.h1x; st.F[MM_F_H1_VX * A + i] = v.h1vx;
+  st.F[MM_F_H2_X * A + i] = v.h2x; st.F[MM_F_H2_VX * A + i] = v.h2vx;
   st.B[MM_B_LANE * A + i] = (uint8_t)v.lane; st.B[MM_B_TARGET_LANE * A + i] = (uint8_t)v.tlane;
   st.B[MM_B_SPEED_INDEX * A + i] = (uint8_t)v.sidx; st.B[MM_B_CRASHED * A + i] = (uint8_t)v.crashed;
   st.B[MM_B_HL_ACTION * A + i] = (uint8_t)v.hl; st.B[MM_B_FLAGS * A + i] = (uint8_t)v.flags;
@@ -255,8 +251,7 @@ MM_DEV void init_vehicle(Veh &v) {  // kinematics.py:36-53, controller.py:35-50,
   v.act_steer = v.act_acc = 0;
   v.safe_steer = v.safe_acc = 0;
   v.gvx = __builtin_nan("");
-  v.h1x = v.h1h = v.h1vx = v.h1v = 0;
-  v.h2x = v.h2h = v.h2vx = v.h2v = 0;
+  v.h1x = v.h1vx = v.h2x = v.h2vx = 0;
   v.crashed = 0; v.hl = MM_HL_NONE; v.flags = 0; v.hist_len = 0;
 }
 MM_DEV int spawn_vehicle(Veh &v, int a, int N, uint64_t seed, uint32_t episode) {
@@ -349,30 +344,21 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
     // normalize_obs :181-193 via utils.lmap :16-18 (no clip); ranges :171-176, :238-239
     const double lo[5] = {-5.0 * 30, -12, -1.5 * 30, -1.5 * 30, -kPi / 2};
     const double hi[5] = {5.0 * 30, 12, 1.5 * 30, 1.5 * 30, kPi / 2};
-    double o[5 * F];
+    const double ego[5] = {v.x, v.y, vx, vy, v.h};
+    auto put = [&](int k, double val) {
+      if (c.obs_f64) ((double *)obs)[i * (5 * F) + k] = val;
+      else ((float *)obs)[i * (5 * F) + k] = (float)val;
+    };
+    put(0, v.present ? 1.0 : 0.0);
 #pragma unroll
-    for (int k = 0; k < 5 * F; k++) o[k] = 0;
-    if (v.present) {
-      const double ego[5] = {v.x, v.y, vx, vy, v.h};
-      o[0] = 1;
+    for (int f = 0; f < F - 1; f++) put(1 + f, v.present ? (-1 + (ego[f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f])) : 0.0);
 #pragma unroll
-      for (int f = 0; f < F - 1; f++) o[1 + f] = -1 + (ego[f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f]);
+    for (int q = 0; q < 4; q++) {
+      const bool hq = v.present && have[q];
+      put((q + 1) * F, hq ? 1.0 : 0.0);
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        o[(q + 1) * F] = have[q] ? 1 : 0;
-#pragma unroll
-        for (int f = 0; f < F - 1; f++)
-          o[(q + 1) * F + 1 + f] = have[q] ? (-1 + (row[q][f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f])) : 0;
-      }
-    }
-    if (c.obs_f64) {
-      double *dst = (double *)obs + i * (5 * F);
-#pragma unroll
-      for (int k = 0; k < 5 * F; k++) dst[k] = o[k];
-    } else {
-      float *dst = (float *)obs + i * (5 * F);
-#pragma unroll
-      for (int k = 0; k < 5 * F; k++) dst[k] = (float)o[k];
+      for (int f = 0; f < F - 1; f++)
+        put((q + 1) * F + 1 + f, hq ? (-1 + (row[q][f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f])) : 0.0);
     }
   }
   // action mask: with masking on, the reference's `[[0]*n_a]*n` aliases every row (abstract.py:202,475)
@@ -542,8 +528,11 @@ MM_DEV Rel relate(double ex, double ey, int elane, int enl, bool other, double o
 // ------------------------------------------------------------------------------------------------
 // the fused step kernel
 // ------------------------------------------------------------------------------------------------
+#ifndef MM_MIN_WAVES
+#define MM_MIN_WAVES 2  // 2 waves/SIMD: measured 0.62 ms vs 0.98 (1) / 0.92 (3, spills) at 65536x8 MASS
+#endif
 template <int G, int KIND, int SHIELD>
-__global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
+__global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
                                                    MMStepOut out, double *metrics) {
   constexpr bool LC = (KIND == MM_ENV_V1);
   constexpr bool SHIELDED = LC && (SHIELD != MM_SHIELD_NONE);
@@ -807,8 +796,8 @@ __global__ __launch_bounds__(256) void step_kernel(DevCfg c, DevState st, const 
       if (LC) {
         v.safe_steer = (SHIELDED && shield_on && veto) ? steerB : v.act_steer;
         v.safe_acc = acc; v.gvx = cc.gvx;
-        v.h2x = v.h1x; v.h2h = v.h1h; v.h2vx = v.h1vx; v.h2v = v.h1v;  // log_step :187-201
-        v.h1x = v.x; v.h1h = v.h; v.h1vx = v.v * cc.cpsi; v.h1v = v.v;
+        v.h2x = v.h1x; v.h2vx = v.h1vx;  // log_step :187-201
+        v.h1x = v.x; v.h1vx = v.v * cc.cpsi;
         if (v.hist_len < 2) v.hist_len++;
       }
       if (SHIELDED) { cpsi = cc.cpsi; offL = cc.offL; offR = cc.offR; nl_self = cc.nl; }

@@ -18,7 +18,8 @@ import torch
 from . import _cabi as abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB = os.path.join(_HERE, "csrc", "libmm_hip.so")
+# MM_HIP_LIB: kernel-tuning experiments load an alternative build of the SAME library (never the oracle)
+HIP_LIB = os.environ.get("MM_HIP_LIB") or os.path.join(_HERE, "csrc", "libmm_hip.so")
 
 
 def _ptr(t):

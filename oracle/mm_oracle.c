@@ -83,7 +83,7 @@ typedef struct {
   double act_steer, act_acc;   /* self.action */
   double safe_steer, safe_acc; /* self.safe_action */
   double g_vx;                 /* fg_params["g"]["vx"] */
-  double h1[4], h2[4];         /* state_hist[-1], [-2]: x, heading, vx, speed */
+  double h1[2], h2[2];         /* state_hist[-1], [-2]: x, vx (all the shield reads of a record) */
   int lane, target_lane, speed_index, crashed, hl_action, flags, hist_len, kind;
   double local_reward, regional_reward;
   /* trace of the last shield call */
@@ -420,7 +420,7 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
         s_oar.vx = o->speed * m_cos(o->heading); s_oar.speed = o->speed;
       } else if (!s_oa.present && ld >= 0) {
         s_oa.present = 1; /* veh.state_hist[-2] */
-        s_oa.x = o->h2[0]; s_oa.heading = o->h2[1]; s_oa.vx = o->h2[2]; s_oa.speed = o->h2[3];
+        s_oa.x = o->h2[0]; s_oa.vx = o->h2[1]; /* heading / speed only feed the unused dpsi term */
         if (mass) {
           a_oa_acc = o->safe_acc; a_oa_steer = o->safe_steer; gp_oa = o->g_vx;
           /* :138-160: the corner test always overrides the collaborate_adj expression */
@@ -432,7 +432,7 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
       }
     } else if (!s_ol.present && (is_same_lane(veh, o->lane) || appr) && ld > 0) {
       s_ol.present = 1;
-      s_ol.x = o->h2[0]; s_ol.heading = o->h2[1]; s_ol.vx = o->h2[2]; s_ol.speed = o->h2[3];
+      s_ol.x = o->h2[0]; s_ol.vx = o->h2[1];
       if (mass) { a_ol_acc = o->safe_acc; a_ol_steer = o->safe_steer; gp_ol = o->g_vx; }
     }
   }
@@ -591,8 +591,7 @@ static int vehicle_step(const MMConfig *cfg, Env *e, int i, double dt) {
   v->lane = closest_lane(v->x, v->y, v->heading); /* on_state_update kinematics.py:154-159 */
   if (is_lc) { /* log_step: state_hist.append(to_dict()) safe_controller.py:187-201 */
     memcpy(v->h2, v->h1, sizeof v->h1);
-    v->h1[0] = v->x; v->h1[1] = v->heading; v->h1[2] = v->speed * m_cos(v->heading);
-    v->h1[3] = v->speed;
+    v->h1[0] = v->x; v->h1[1] = v->speed * m_cos(v->heading);
     if (v->hist_len < 2) v->hist_len++;
   }
   return rc;
@@ -902,7 +901,7 @@ static void load_env(const struct MMHandle_ *h, int64_t e_idx, Env *e) {
     v->speed = F[MM_F_SPEED * A + i]; v->target_speed = F[MM_F_TARGET_SPEED * A + i];
     v->safe_steer = F[MM_F_SAFE_STEER * A + i]; v->safe_acc = F[MM_F_SAFE_ACC * A + i];
     v->g_vx = F[MM_F_G_VX * A + i];
-    for (int k = 0; k < 4; k++) { v->h1[k] = F[(MM_F_H1_X + k) * A + i]; v->h2[k] = F[(MM_F_H2_X + k) * A + i]; }
+    for (int k = 0; k < 2; k++) { v->h1[k] = F[(MM_F_H1_X + k) * A + i]; v->h2[k] = F[(MM_F_H2_X + k) * A + i]; }
     v->lane = B[MM_B_LANE * A + i]; v->target_lane = B[MM_B_TARGET_LANE * A + i];
     v->speed_index = B[MM_B_SPEED_INDEX * A + i]; v->crashed = B[MM_B_CRASHED * A + i];
     v->hl_action = B[MM_B_HL_ACTION * A + i]; v->flags = B[MM_B_FLAGS * A + i];
@@ -924,7 +923,7 @@ static void store_env(struct MMHandle_ *h, int64_t e_idx, const Env *e) {
     F[MM_F_SPEED * A + i] = v->speed; F[MM_F_TARGET_SPEED * A + i] = v->target_speed;
     F[MM_F_SAFE_STEER * A + i] = v->safe_steer; F[MM_F_SAFE_ACC * A + i] = v->safe_acc;
     F[MM_F_G_VX * A + i] = v->g_vx;
-    for (int k = 0; k < 4; k++) { F[(MM_F_H1_X + k) * A + i] = v->h1[k]; F[(MM_F_H2_X + k) * A + i] = v->h2[k]; }
+    for (int k = 0; k < 2; k++) { F[(MM_F_H1_X + k) * A + i] = v->h1[k]; F[(MM_F_H2_X + k) * A + i] = v->h2[k]; }
     B[MM_B_LANE * A + i] = (uint8_t)v->lane; B[MM_B_TARGET_LANE * A + i] = (uint8_t)v->target_lane;
     B[MM_B_SPEED_INDEX * A + i] = (uint8_t)v->speed_index; B[MM_B_CRASHED * A + i] = (uint8_t)v->crashed;
     B[MM_B_HL_ACTION * A + i] = (uint8_t)v->hl_action; B[MM_B_FLAGS * A + i] = (uint8_t)v->flags;

@@ -54,15 +54,13 @@ def _force_state(env, z, meta, t, s_at):
                       ("TARGET_SPEED", "target_speed"), ("SAFE_STEER", "safe_steer"), ("SAFE_ACC", "safe_acc"),
                       ("G_VX", "g_vx")):
         put(env.f64[F[name]], gf[:, SF[col]])
-    h1 = np.stack([gf[:, SF["x"]], gf[:, SF["heading"]], gf[:, SF["speed"]] * np.cos(gf[:, SF["heading"]]),
-                   gf[:, SF["speed"]]])
+    h1 = np.stack([gf[:, SF["x"]], gf[:, SF["speed"]] * np.cos(gf[:, SF["heading"]])])
     if s_at >= 2:
         pf = z["sub_f"][s_at - 2]
-        h2 = np.stack([pf[:, SF["x"]], pf[:, SF["heading"]], pf[:, SF["speed"]] * np.cos(pf[:, SF["heading"]]),
-                       pf[:, SF["speed"]]])
+        h2 = np.stack([pf[:, SF["x"]], pf[:, SF["speed"]] * np.cos(pf[:, SF["heading"]])])
     else:
-        h2 = np.zeros((4, n))
-    for k, nm in enumerate(("X", "HEADING", "VX", "SPEED")):
+        h2 = np.zeros((2, n))
+    for k, nm in enumerate(("X", "VX")):
         put(env.f64[F["H1_" + nm]], h1[k])
         put(env.f64[F["H2_" + nm]], h2[k])
     put(env.u8[B["LANE"]], gi[:, SI["lane"]])
