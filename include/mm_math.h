@@ -142,7 +142,7 @@ MMM_FN double mmm_tan(double x) {
 MMM_FN double mmm_atan01(double ax, double *lo_out) {
   int j = (int)(4.0 * ax + 0.5);
   double c = 0.25 * (double)j;
-  double t = (j == 0) ? ax : (ax - c) / fma(ax, c, 1.0);
+  double t = (ax - c) / fma(ax, c, 1.0); /* j == 0: (ax - 0) / 1 == ax exactly, no special case needed */
   double z = t * t;
   double p = MMM_A10;
   p = fma(p, z, MMM_A9); p = fma(p, z, MMM_A8); p = fma(p, z, MMM_A7); p = fma(p, z, MMM_A6);
@@ -155,19 +155,20 @@ MMM_FN double mmm_atan01(double ax, double *lo_out) {
   return hi + (pt + lo);
 }
 MMM_FN double mmm_atan(double x) {
-  double ax = fabs(x), lo;
-  double r;
-  if (ax > 1.0) r = MMM_PIO2_HI - (mmm_atan01(1.0 / ax, &lo) - MMM_PIO2_LO);
-  else r = mmm_atan01(ax, &lo);
+  double ax = fabs(x), lo, z = ax;
+  const int inv = ax > 1.0;
+  if (inv) z = 1.0 / ax; /* rare on this path (arguments are slopes < 1): a skipped branch, one atan01 body */
+  double r = mmm_atan01(z, &lo);
+  if (inv) r = MMM_PIO2_HI - (r - MMM_PIO2_LO);
   return x < 0 ? -r : r;
 }
 /* asin(x) = atan2(|x|, sqrt((1-|x|)(1+|x|))), |x| <= 1 */
 MMM_FN double mmm_asin(double x) {
   double y = fabs(x), lo;
   double w = sqrt((1.0 - y) * (1.0 + y));
-  double r;
-  if (y <= w) r = mmm_atan01(y / w, &lo);
-  else r = MMM_PIO2_HI - (mmm_atan01(w / y, &lo) - MMM_PIO2_LO);
+  const int direct = y <= w;
+  double r = mmm_atan01((direct ? y : w) / (direct ? w : y), &lo); /* one division, one polynomial */
+  if (!direct) r = MMM_PIO2_HI - (r - MMM_PIO2_LO);
   return x < 0 ? -r : r;
 }
 /* exp: x = k ln2 + r, |r| <= ln2/2, Taylor to r^14, exact scaling */

@@ -38,12 +38,28 @@ MM_DEV int lane_road(int l) { return l == 0 ? 0 : (l <= 2 ? 1 : l - 1); }  // (f
 MM_DEV int lane_rid(int l) { return l == MM_LANE_BC1 ? 1 : 0; }            // lane id within the road
 
 // ---- utils.py ---------------------------------------------------------------------------------
-MM_DEV double py_mod(double a, double b) {  // Python float %: result takes the divisor's sign
-  double m = fmod(a, b);
+// C fmod(a, b) for b > 0, exact like the libm one.  |a| < 2b (every heading difference on this path)
+// needs no division: the result is a, or a -/+ b (exact by Sterbenz).  Otherwise q = floor(|a|/b) can
+// be one too large only when |a|/b rounds up to an integer; r = fma(-q, b, |a|) is exact either
+// way (the true remainder is a multiple of ulp(b) below b) and one exact correction fixes it.
+MM_DEV double fmod_pos(double a, double b) {
+  const double aa = fabs(a);
+  double r;
+  if (aa < b) r = aa;
+  else if (aa < 2 * b) r = aa - b;
+  else {
+    const double q = floor(aa / b);
+    r = fma(-q, b, aa);
+    if (r < 0) r += b;
+  }
+  return a < 0 ? -r : r;
+}
+MM_DEV double py_mod(double a, double b) {  // Python float % for b > 0: result in [0, b)
+  double m = fmod_pos(a, b);
   if (m != 0.0) {
-    if ((b < 0) != (m < 0)) m += b;
+    if (m < 0) m += b;
   } else {
-    m = copysign(0.0, b);
+    m = 0.0;  // copysign(0, b)
   }
   return m;
 }
@@ -153,7 +169,7 @@ MM_DEV bool has_corner_inside(double c1x, double c1y, double l1, double w1, doub
     double rx = c * px[k] + (-s) * py[k], ry = s * px[k] + c * py[k];
     double dx = (c1x + rx) - c2x, dy = (c1y + ry) - c2y;
     double ru0 = c2 * dx + (-s2) * dy, ru1 = s2 * dx + c2 * dy;
-    any = any || ((-l2 / 2 <= ru0 && ru0 <= l2 / 2) && (-w2 / 2 <= ru1 && ru1 <= w2 / 2));
+    any |= ((-l2 / 2 <= ru0) & (ru0 <= l2 / 2)) & ((-w2 / 2 <= ru1) & (ru1 <= w2 / 2));  // no short-circuit branches
   }
   return any;
 }

@@ -28,7 +28,7 @@
 using namespace mm;
 
 struct DevCfg {
-  int env_kind, shield, nsub, T, action_masking, auto_reset, obs_f64, N, debug_flags;
+  int env_kind, shield, nsub, T, action_masking, auto_reset, obs_f64, N, E, debug_flags;
   double dt, collision_reward, high_speed_reward, headway_cost, headway_time, merging_lane_cost;
   double rs_lo, rs_hi, eta, tau;
 };
@@ -165,17 +165,24 @@ MM_DEV void controlled_act(Veh &v, int action) {
   v.act_acc = (1 / kTauA) * (v.tspeed - v.v);  // speed_control :189-197
   v.act_steer = clipd(steer, -kPi / 3, kPi / 3);
 }
-// controller.py:293-311 MDPVehicle.act (+ safe_controller.py:63-66 hl_action)
+// The high-level act of a policy step: action_type.act -> MDPLCVehicle.act / MDPVehicle.act /
+// ControlledVehicle.act (safe_controller.py:63-66, controller.py:293-311, :90-125).  Road.act()
+// runs ControlledVehicle.act() again right after (abstract.py:516-521) and overwrites the steering
+// / acceleration this call computes, so only its side effects are kept: hl_action, speed index /
+// target speed, follow_road and the lane-change target.
 template <int KIND>
-MM_DEV void mdp_act(Veh &v, int action) {
+MM_DEV void hl_act(Veh &v, int action) {
   if (KIND == MM_ENV_V1 && action >= 0) v.hl = action;
   if (action == 3 || action == 4) {
     int si = speed_to_index(v.v) + (action == 3 ? 1 : -1);
     v.sidx = si < 0 ? 0 : (si > 4 ? 4 : si);
     v.tspeed = index_to_speed(v.sidx);
-    controlled_act(v, -1);
-  } else {
-    controlled_act(v, action);
+  }
+  if (lane_after_end(v.tlane, v.x)) v.tlane = next_lane(v.tlane, v.x, v.y);  // follow_road :136-144
+  if (action == 2 || action == 0) {
+    int cand = v.tlane;
+    if (lane_road(v.tlane) == 1) cand = (action == 2) ? MM_LANE_BC1 : MM_LANE_BC0;
+    if (lane_reachable(cand, v.x, v.y)) v.tlane = cand;
   }
 }
 
@@ -340,15 +347,11 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
       }
     }
   });
-  if (valid && obs) {
-    // normalize_obs :181-193 via utils.lmap :16-18 (no clip); ranges :171-176, :238-239
-    const double lo[5] = {-5.0 * 30, -12, -1.5 * 30, -1.5 * 30, -kPi / 2};
-    const double hi[5] = {5.0 * 30, 12, 1.5 * 30, 1.5 * 30, kPi / 2};
-    const double ego[5] = {v.x, v.y, vx, vy, v.h};
-    auto put = [&](int k, double val) {
-      if (c.obs_f64) ((double *)obs)[i * (5 * F) + k] = val;
-      else ((float *)obs)[i * (5 * F) + k] = (float)val;
-    };
+  // normalize_obs :181-193 via utils.lmap :16-18 (no clip); ranges :171-176, :238-239
+  const double lo[5] = {-5.0 * 30, -12, -1.5 * 30, -1.5 * 30, -kPi / 2};
+  const double hi[5] = {5.0 * 30, 12, 1.5 * 30, 1.5 * 30, kPi / 2};
+  const double ego[5] = {v.x, v.y, vx, vy, v.h};
+  auto emit = [&](auto put) {
     put(0, v.present ? 1.0 : 0.0);
 #pragma unroll
     for (int f = 0; f < F - 1; f++) put(1 + f, v.present ? (-1 + (ego[f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f])) : 0.0);
@@ -359,6 +362,32 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
 #pragma unroll
       for (int f = 0; f < F - 1; f++)
         put((q + 1) * F + 1 + f, hq ? (-1 + (row[q][f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f])) : 0.0);
+    }
+  };
+  if (obs && c.obs_f64) {
+    if (valid) emit([&](int k, double val) { ((double *)obs)[i * (5 * F) + k] = val; });
+  } else if (obs) {
+    // float32 rows: stage the wave's rows in LDS, then write them as ONE contiguous run per wave
+    // (a lane's 5F floats are 100/120 B apart from its neighbour's: direct stores would touch 64
+    // different cache lines per instruction and tripled the measured WRITE_SIZE).
+    constexpr int S = 5 * F;
+    __shared__ float s_obs[4][64 * S];
+    float *sw = s_obs[threadIdx.x >> 6];
+    const int lane = lane_id();
+    const int slot = (lane / G) * c.N + a;  // valid lanes of a wave are contiguous in agent index
+    if (valid) emit([&](int k, double val) { sw[slot * S + k] = (float)val; });
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const long long e0 = (i - a) / c.N - lane / G;  // first env of this wave (i = e*N + a on every lane)
+    long long nenv = (long long)c.E - e0;
+    nenv = nenv < 0 ? 0 : (nenv > 64 / G ? 64 / G : nenv);
+    const int total = (int)nenv * c.N * S;
+    float *dst = (float *)obs + e0 * c.N * S;
+    if constexpr (S % 2 == 0) {
+      for (int t = lane; t < total / 2; t += 64) ((float2 *)dst)[t] = ((const float2 *)sw)[t];
+    } else {
+      for (int t = lane; t < total; t += 64) dst[t] = sw[t];
     }
   }
   // action mask: with masking on, the reference's `[[0]*n_a]*n` aliases every row (abstract.py:202,475)
@@ -573,8 +602,8 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     QpTrace qt = {0, __builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan(""),
                   __builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
     if (live) {
-      if (time % c.nsub == 0) mdp_act<KIND>(v, action);  // action_type.act abstract.py:516-519
-      mdp_act<KIND>(v, -1);                              // road.act road.py:269-278
+      if (time % c.nsub == 0) hl_act<KIND>(v, action);  // action_type.act abstract.py:516-519
+      controlled_act(v, -1);                             // road.act road.py:269-278
       clip_actions<KIND>(v);
     }
     // predicted post-state for the nominal steering (the only one when nothing vetoes)
@@ -1140,7 +1169,7 @@ static DevCfg dev_cfg(const MMHandle h) {
   DevCfg d;
   d.env_kind = c.env_kind; d.shield = c.env_kind == MM_ENV_V1 ? c.shield : MM_SHIELD_NONE;
   d.nsub = c.simulation_frequency / c.policy_frequency; d.T = c.duration * c.policy_frequency;
-  d.action_masking = c.action_masking; d.auto_reset = c.auto_reset; d.obs_f64 = c.obs_f64; d.N = h->N;
+  d.action_masking = c.action_masking; d.auto_reset = c.auto_reset; d.obs_f64 = c.obs_f64; d.N = h->N; d.E = h->E;
   d.debug_flags = c.debug_flags;
   d.dt = 1.0 / c.simulation_frequency;
   d.collision_reward = c.collision_reward; d.high_speed_reward = c.high_speed_reward;
@@ -1174,12 +1203,16 @@ static void launch_reset_g(MMHandle h, int mode, const uint8_t *mask, const uint
 static int launch_reset(MMHandle h, int mode, const uint8_t *mask, const uint64_t *seeds, void *obs,
                         uint8_t *avail, MMStream stream) {
   hipStream_t s = (hipStream_t)stream;
+#ifdef MM_ONLY_G8
+  launch_reset_g<8>(h, mode, mask, seeds, obs, avail, s);
+#else
   switch (group_size(h->N)) {
     case 2: launch_reset_g<2>(h, mode, mask, seeds, obs, avail, s); break;
     case 4: launch_reset_g<4>(h, mode, mask, seeds, obs, avail, s); break;
     case 8: launch_reset_g<8>(h, mode, mask, seeds, obs, avail, s); break;
     default: launch_reset_g<16>(h, mode, mask, seeds, obs, avail, s); break;
   }
+#endif
   hipError_t rc = hipGetLastError();
   return rc == hipSuccess ? MM_OK : hip_fail(h, rc, "reset launch");
 }
@@ -1223,12 +1256,16 @@ extern "C" int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *
     hipError_t rc = hipMemsetAsync(out->trace, 0xFF, (size_t)3 * MM_T_COUNT * h->E * h->N * sizeof(double), s);
     if (rc != hipSuccess) return hip_fail(h, rc, "trace memset");
   }
+#ifdef MM_ONLY_G8  // tuning builds: one instantiation, seconds to compile
+  launch_step_g<8>(h, actions, out, s);
+#else
   switch (group_size(h->N)) {
     case 2: launch_step_g<2>(h, actions, out, s); break;
     case 4: launch_step_g<4>(h, actions, out, s); break;
     case 8: launch_step_g<8>(h, actions, out, s); break;
     default: launch_step_g<16>(h, actions, out, s); break;
   }
+#endif
   hipError_t rc = hipGetLastError();
   return rc == hipSuccess ? MM_OK : hip_fail(h, rc, "step launch");
 }
