@@ -243,7 +243,8 @@ const char *mm_last_error(MMHandle h);
 
 /*
  * Diagnostics: evaluate one elementary function of include/mm_math.h element-wise
- * (fn: 0 sin, 1 cos, 2 tan, 3 atan, 4 asin, 5 exp, 6 log, 7 sqrt, 8 x/y with y = x2[i]).
+ * (fn: 0 sin, 1 cos, 2 tan, 3 atan, 4 asin, 5 exp, 6 log, 7 sqrt, 8 x/y with y = x2[i],
+ * 9 x/y through the HIP path's constant-divisor form div_c (the oracle uses plain division)).
  * x, x2 (may be NULL unless fn == 8), y: DEV double[n].  Used to prove CPU/GPU bit equality.
  */
 int32_t mm_math_eval(int32_t fn, int32_t n, const double *x, const double *x2, double *y, MMStream stream);

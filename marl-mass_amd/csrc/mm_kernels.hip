@@ -31,6 +31,7 @@ struct DevCfg {
   int env_kind, shield, nsub, T, action_masking, auto_reset, obs_f64, N, E, debug_flags;
   double dt, collision_reward, high_speed_reward, headway_cost, headway_time, merging_lane_cost;
   double rs_lo, rs_hi, eta, tau;
+  double inv_dt, rs_span, rs_ispan;  // host-computed reciprocals for div_c (correctly rounded 1/d)
 };
 struct DevState {
   double *F;
@@ -223,7 +224,7 @@ MM_DEV Cand predict(const Veh &v, double steer, double dt) {
   double vx = v.v * mmm_cos(v.h + beta), vy = v.v * mmm_sin(v.h + beta);
   c.x = v.x + vx * dt;
   c.y = v.y + vy * dt;
-  c.h = v.h + v.v * mmm_sin(beta) / (kVehLength / 2) * dt;
+  c.h = v.h + MM_DIVC(v.v * mmm_sin(beta), 2.5) * dt;  // / (LENGTH / 2)
   c.gvx = (KIND == MM_ENV_V1) ? mmm_cos(c.h + beta) : 0.0;
   c.lane = closest_lane(c.x, c.y, c.h);  // on_state_update kinematics.py:154-159
   c.cpsi = (KIND == MM_ENV_V1) ? mmm_cos(c.h) : 0.0;
@@ -349,19 +350,21 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
   });
   // normalize_obs :181-193 via utils.lmap :16-18 (no clip); ranges :171-176, :238-239
   const double lo[5] = {-5.0 * 30, -12, -1.5 * 30, -1.5 * 30, -kPi / 2};
-  const double hi[5] = {5.0 * 30, 12, 1.5 * 30, 1.5 * 30, kPi / 2};
+  const double span[5] = {300.0, 24.0, 90.0, 90.0, kPi / 2 - (-kPi / 2)};  // x[1] - x[0] of lmap
+  const double ispan[5] = {1.0 / 300.0, 1.0 / 24.0, 1.0 / 90.0, 1.0 / 90.0, 1.0 / (kPi / 2 - (-kPi / 2))};
+  auto lmap = [&](double val, int f) { return -1 + div_c((val - lo[f]) * (1 - (-1)), span[f], ispan[f]); };
   const double ego[5] = {v.x, v.y, vx, vy, v.h};
   auto emit = [&](auto put) {
     put(0, v.present ? 1.0 : 0.0);
 #pragma unroll
-    for (int f = 0; f < F - 1; f++) put(1 + f, v.present ? (-1 + (ego[f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f])) : 0.0);
+    for (int f = 0; f < F - 1; f++) put(1 + f, v.present ? lmap(ego[f], f) : 0.0);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const bool hq = v.present && have[q];
       put((q + 1) * F, hq ? 1.0 : 0.0);
 #pragma unroll
       for (int f = 0; f < F - 1; f++)
-        put((q + 1) * F + 1 + f, hq ? (-1 + (row[q][f] - lo[f]) * (1 - (-1)) / (hi[f] - lo[f])) : 0.0);
+        put((q + 1) * F + 1 + f, hq ? lmap(row[q][f], f) : 0.0);
     }
   };
   if (obs && c.obs_f64) {
@@ -448,81 +451,104 @@ MM_DEV unsigned obstacle_override(Neigh &nb, double x, double y) {  // decentral
   }
   return replaced;
 }
+// Everything of the shield that does not depend on the neighbours' DECIDED accelerations
+// (evaluated once per classification); shield_dyn() finishes it per fixed-point round.
+struct ShieldStatic {
+  double evx, u0, g0, g2, g4, g6, u6, v_min, v_max, h1, h2;
+  double px_lon, px_lona, px_lonr, q_lon, q_lona, q_lonr, hls_lona, hls_lonr;
+  double base0, base3;  // h0 / h3 without their g*u terms
+  bool cadj, can_abort_lc;
+};
 template <bool MASS>
-MM_DEV ShieldOut shield_eval(const DevCfg &c, const Veh &v, double cpsi, bool offL, bool offR, const Neigh &nb) {
+MM_DEV ShieldStatic shield_static(const DevCfg &c, const Veh &v, double cpsi, bool offL, bool offR, const Neigh &nb) {
   const double dt = c.dt, eta = c.eta;
-  ShieldOut o;
-  double v_min = v.v + kLcMinAcc * dt;
-  if (MASS) v_min = v_min > 0 ? v_min : 0;  // :798
-  const double v_max = v.v + kLcMaxAcc * dt;
+  ShieldStatic s;
+  s.v_min = v.v + kLcMinAcc * dt;
+  if (MASS) s.v_min = s.v_min > 0 ? s.v_min : 0;  // :798
+  s.v_max = v.v + kLcMaxAcc * dt;
   double evx = v.v * cpsi;
-  evx = evx > 1 ? evx : 1;  // :307-309
+  s.evx = evx > 1 ? evx : 1;  // :307-309
   const double x_e = v.x;
   const double x_ol = nb.has_ol ? nb.ol_x : x_e + kPerception + 1;
   const double x_oa = nb.has_oa ? nb.oa_x : x_e + kPerception + 1;
   const double x_oar = nb.has_oar ? nb.oar_x : x_e - kPerception - 1;
-  const double g0 = v.gvx * dt;
-  const double g2 = MASS ? nb.ol_g * dt : 1 * dt;
-  const double g4 = MASS ? nb.oa_g * dt : 1 * dt;
-  const double g6 = 1 * dt;
+  s.g0 = v.gvx * dt;
+  s.g2 = MASS ? nb.ol_g * dt : 1 * dt;
+  s.g4 = MASS ? nb.oa_g * dt : 1 * dt;
+  s.g6 = 1 * dt;
   double sv_oar = nb.has_oar ? nb.oar_vx : 0;
   sv_oar = sv_oar + kCbfAccHi * dt;
   sv_oar = sv_oar > 1 ? sv_oar : 1;
   const double buffer = (kCbfAccHi + 0.1) * dt * c.tau;
-  const double sd0 = evx * c.tau + kVehLength + buffer;
+  const double sd0 = s.evx * c.tau + kVehLength + buffer;
   const double sd2 = sv_oar * c.tau + kVehLength + buffer;
-  // simplified_control (:60-77)
-  double u0 = evx + v.act_acc * dt; u0 = u0 > 0 ? u0 : 0;
-  double u2 = 0, u4 = 0, u6 = 0;
+  double u0 = s.evx + v.act_acc * dt;  // simplified_control (:60-77)
+  s.u0 = u0 > 0 ? u0 : 0;
+  s.u6 = 0;
+  if (nb.has_oar) { double u6 = nb.oar_vx + kCbfAccHi * dt; s.u6 = u6 > 0 ? u6 : 0; }
+  s.cadj = MASS && nb.constrain_adj;
+  s.q_lon = -kVehLength - sd0;
+  s.q_lona = -kVehLength - sd0;
+  s.q_lonr = -kVehLength - sd2;
+  if (s.cadj) s.q_lona = -kVehLength - sd0 - kAdjBuffer;
+  s.px_lon = x_ol - x_e; s.px_lona = x_oa - x_e; s.px_lonr = x_e - x_oar;
+  s.base0 = s.px_lon + (eta - 1) * s.px_lon + eta * s.q_lon;
+  s.base3 = s.px_lona + (eta - 1) * s.px_lona + eta * s.q_lona;
+  s.h1 = s.v_max - s.u0;
+  s.h2 = -s.v_min + s.u0;
+  s.hls_lona = s.px_lona + s.q_lona;
+  s.hls_lonr = s.px_lonr + s.q_lonr;
+  s.can_abort_lc = !offL && !offR;  // :728-736 on the pre-step pose
+  return s;
+}
+template <bool MASS>
+MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s, const Neigh &nb) {
+  const double dt = c.dt, eta = c.eta;
+  ShieldOut o;
+  double u2 = 0, u4 = 0;
   if (nb.has_ol) { u2 = nb.ol_vx + nb.ol_acc * dt; u2 = u2 > 0 ? u2 : 0; }
   if (nb.has_oa) { u4 = nb.oa_vx + nb.oa_acc * dt; u4 = u4 > 0 ? u4 : 0; }
-  if (nb.has_oar) { u6 = nb.oar_vx + kCbfAccHi * dt; u6 = u6 > 0 ? u6 : 0; }
-  const bool cadj = MASS && nb.constrain_adj;
-  const double q_lon = -kVehLength - sd0;
-  double q_lona = -kVehLength - sd0;
-  const double q_lonr = -kVehLength - sd2;
-  if (cadj) q_lona = -kVehLength - sd0 - kAdjBuffer;
-  const double px_lon = x_ol - x_e, px_lona = x_oa - x_e, px_lonr = x_e - x_oar;
-  const double h0 = px_lon + (eta - 1) * px_lon + eta * q_lon + (-(g0 * u0) + g2 * u2);
-  const double h1 = v_max - u0;
-  const double h2 = -v_min + u0;
+  const double g0u0 = s.g0 * s.u0;
+  const double h0 = s.base0 + (-g0u0 + s.g2 * u2);
   double h3 = __builtin_nan(""), hc = h0;
-  if (cadj) {
-    h3 = px_lona + (eta - 1) * px_lona + eta * q_lona + (-(g0 * u0) + g4 * u4);
+  if (s.cadj) {
+    h3 = s.base3 + (-g0u0 + s.g4 * u4);
     hc = h3 < h0 ? h3 : h0;
   }
   // exact KKT point of min 1/2(d^2 + e^2 + 1e18 s^2) s.t. a d - s <= hc, lo <= d <= hi
   double d;
-  if (g0 > 0) d = fmin(0.0, hc / g0);
-  else if (g0 < 0) d = fmax(0.0, hc / g0);
+  if (s.g0 > 0) d = fmin(0.0, hc / s.g0);
+  else if (s.g0 < 0) d = fmax(0.0, hc / s.g0);
   else d = 0.0;
-  d = fmin(fmax(d, -h2), h1);
-  double us0 = u0 + d;
+  d = fmin(fmax(d, -s.h2), s.h1);
+  double us0 = s.u0 + d;
   // is_lc_allowed (cbf.py:324-339)
-  const double hls_lona = px_lona + q_lona;
-  const double hlds_lona = px_lona + ((-g0) * us0 + g4 * u4) + q_lona;
-  const double hls_lonr = px_lonr + q_lonr;
-  const double hlds_lonr = px_lonr + (g0 * us0 + (-g6) * u6) + q_lonr;
-  const double inv_lona = hlds_lona + (eta - 1) * hls_lona, inv_lonr = hlds_lonr + (eta - 1) * hls_lonr;
-  const bool lc_allowed = ((hls_lona >= 0) && inv_lona >= 0) && ((hls_lonr >= 0) && inv_lonr >= 0);
+  const double hlds_lona = s.px_lona + ((-s.g0) * us0 + s.g4 * u4) + s.q_lona;
+  const double hlds_lonr = s.px_lonr + (s.g0 * us0 + (-s.g6) * s.u6) + s.q_lonr;
+  const double inv_lona = hlds_lona + (eta - 1) * s.hls_lona, inv_lonr = hlds_lonr + (eta - 1) * s.hls_lonr;
+  const bool lc_allowed = ((s.hls_lona >= 0) && inv_lona >= 0) && ((s.hls_lonr >= 0) && inv_lonr >= 0);
   int fl = v.flags & MM_FLAG_COLLABORATE_ADJ;
-  if (cadj) fl |= MM_FLAG_IS_COLLABORATING;
+  if (s.cadj) fl |= MM_FLAG_IS_COLLABORATING;
   bool veto;
   if (!MASS) {
     veto = !lc_allowed;
   } else {
-    const bool can_abort_lc = !offL && !offR;  // :728-736 on the pre-step pose
-    veto = can_abort_lc && !lc_allowed;
-    if (!veto && (v.hl == 2 || v.hl == 0) && v.v < kStoppingSpeed) us0 = u0;  // :746-750
+    veto = s.can_abort_lc && !lc_allowed;
+    if (!veto && (v.hl == 2 || v.hl == 0) && v.v < kStoppingSpeed) us0 = s.u0;  // :746-750
     if (inv_lona >= -1e-6) fl |= MM_FLAG_COLLABORATE_ADJ;  // can_collaborate_adj cbf.py:424-430
     else fl &= ~MM_FLAG_COLLABORATE_ADJ;
   }
   if (!veto) fl |= MM_FLAG_IS_LC_SAFE;
-  o.acc = (us0 - evx) / dt;  // derived_acceleration :80-82
+  o.acc = div_c(us0 - s.evx, dt, c.inv_dt);  // derived_acceleration :80-82
   o.us0 = us0; o.veto = veto; o.flags = fl;
-  o.qt.rows = cadj ? 4 : 3; o.qt.a = g0; o.qt.h0 = h0; o.qt.h1 = h1; o.qt.h2 = h2; o.qt.h3 = h3; o.qt.d = d;
-  o.qt.margin = fmin(fmin(hls_lona, inv_lona), fmin(hls_lonr, inv_lonr));
+  o.qt.rows = s.cadj ? 4 : 3; o.qt.a = s.g0; o.qt.h0 = h0; o.qt.h1 = s.h1; o.qt.h2 = s.h2; o.qt.h3 = h3; o.qt.d = d;
+  o.qt.margin = fmin(fmin(s.hls_lona, inv_lona), fmin(s.hls_lonr, inv_lonr));
   return o;
+}
+template <bool MASS>
+MM_DEV ShieldOut shield_eval(const DevCfg &c, const Veh &v, double cpsi, bool offL, bool offR, const Neigh &nb) {
+  const ShieldStatic s = shield_static<MASS>(c, v, cpsi, offL, offR, nb);
+  return shield_dyn<MASS>(c, v, s, nb);
 }
 
 // Relation of vehicle `o` (as the ego currently sees it) to the ego: the branch conditions of the
@@ -613,16 +639,18 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     if (live) cA = predict<KIND, SHIELDED>(v, v.act_steer, dt);
     cB = cA;
     double steerB = v.act_steer;
-    bool needB = false;
-    if (SHIELDED) {
-      // LC veto re-steers to the CURRENT lane (decentral_layer.py:501-506,739-744); identical to
-      // the nominal command unless a lane change / lane hand-over is under way or the car crashed
-      needB = shield_on && (v.tlane != v.lane || v.crashed);
-      if (needB) {
+    // LC veto re-steers to the CURRENT lane (decentral_layer.py:501-506,739-744); identical to the
+    // nominal command unless a lane change / lane hand-over is under way or the car crashed.
+    // Candidate B is only predicted when a veto actually fires (lazily, below).
+    const bool needB = SHIELDED && shield_on && (v.tlane != v.lane || v.crashed);
+    bool haveB = false;
+    auto make_B = [&]() {
+      if (SHIELDED && needB && !haveB) {
         steerB = steering_control(v.x, v.y, v.h, v.v, v.lane);
         cB = predict<KIND, true>(v, steerB, dt);
+        haveB = true;
       }
-    }
+    };
     double new_acc = v.act_acc;
     bool use_B = false, veto = false;
     int new_flags = v.flags;
@@ -721,19 +749,21 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
           // ---- MASS: fixed point over the decided accelerations (HSS: one evaluation) ----------
           const int src_ol = gb + (j_ol < 0 ? 0 : j_ol), src_oa = gb + (j_oa < 0 ? 0 : j_oa);
           double acc_cur = shield_on ? 0.0 : v.act_acc;  // vehicles without a shield keep their command
+          const ShieldStatic ss = shield_static<MASS>(c, v, cpsi, offL, offR, nb);
           for (int round = 0; round <= st.N; round++) {
             if (MASS) {
               const double da = shfl_d(acc_cur, src_ol), db = shfl_d(acc_cur, src_oa);
               if (ol_dyn) nb.ol_acc = da;
               if (oa_dyn) nb.oa_acc = db;
             }
-            so = shield_eval<MASS>(c, v, cpsi, offL, offR, nb);
+            so = shield_dyn<MASS>(c, v, ss, nb);
             const double acc_next = shield_on ? so.acc : v.act_acc;
             const bool changed = __double_as_longlong(acc_next) != __double_as_longlong(acc_cur);
             acc_cur = acc_next;
             if (!MASS || !__any(changed)) break;
           }
           const bool want_B = shield_on && so.veto && needB;
+          if (want_B) make_B();
           const bool flip = want_B != use_B;
           use_B = want_B;
           if (!__any(flip)) break;
@@ -745,6 +775,7 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
       }
       if (serial) {
         // ------------- literal front-to-back sweep (fallback / validation form) -----------------
+        make_B();
         use_B = false; veto = false; new_acc = v.act_acc; new_flags = v.flags;
         // working copy of what the others see of me; committed stage by stage
         double wx = v.x, wy = v.y, wh = v.h, wg = v.gvx, wacc = v.safe_acc, wvx = v.v * cpsi;
@@ -931,9 +962,9 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
   // _agent_reward merge_env_v1.py:64-89
   double local = 0;
   if (v.present) {
-    double scaled = 0 + (v.v - c.rs_lo) * (1 - 0) / (c.rs_hi - c.rs_lo);
+    double scaled = 0 + div_c((v.v - c.rs_lo) * (1 - 0), c.rs_span, c.rs_ispan);
     double merging = 0;
-    if (v.lane == MM_LANE_BC1) { double t = v.x - 420; merging = -mmm_exp(-(t * t) / (10 * 100)); }
+    if (v.lane == MM_LANE_BC1) { double t = v.x - 420; merging = -mmm_exp(MM_DIVC(-(t * t), 1000.0)); }
     double hc = v.v > 0 ? mmm_log(hd / (c.headway_time * v.v)) : 0;
     local = c.collision_reward * (-1 * v.crashed) + (c.high_speed_reward * clipd(scaled, 0, 1)) +
             c.merging_lane_cost * merging + c.headway_cost * (hc < 0 ? hc : 0);
@@ -1175,6 +1206,7 @@ static DevCfg dev_cfg(const MMHandle h) {
   d.collision_reward = c.collision_reward; d.high_speed_reward = c.high_speed_reward;
   d.headway_cost = c.headway_cost; d.headway_time = c.headway_time; d.merging_lane_cost = c.merging_lane_cost;
   d.rs_lo = c.reward_speed_lo; d.rs_hi = c.reward_speed_hi; d.eta = c.cbf_eta; d.tau = c.cbf_tau;
+  d.inv_dt = 1.0 / d.dt; d.rs_span = d.rs_hi - d.rs_lo; d.rs_ispan = 1.0 / d.rs_span;
   return d;
 }
 static DevState dev_state(const MMHandle h) {
@@ -1295,13 +1327,14 @@ __global__ void math_kernel(int fn, int n, const double *__restrict__ x, const d
     case 5: r = mmm_exp(v); break;
     case 6: r = mmm_log(v); break;
     case 7: r = sqrt(v); break;
+    case 9: r = div_c(v, x2[i], 1.0 / x2[i]); break;
     default: r = v / x2[i]; break;
   }
   y[i] = r;
 }
 extern "C" int32_t mm_math_eval(int32_t fn, int32_t n, const double *x, const double *x2, double *y,
                                 MMStream stream) {
-  if (fn < 0 || fn > 8 || n <= 0) return MM_ERR_INVALID_ARG;
+  if (fn < 0 || fn > 9 || n <= 0) return MM_ERR_INVALID_ARG;
   hipLaunchKernelGGL(math_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, fn, n, x, x2, y);
   return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_DEVICE;
 }

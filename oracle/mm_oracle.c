@@ -1167,6 +1167,7 @@ int32_t mm_math_eval(int32_t fn, int32_t n, const double *x, const double *x2, d
       case 6: y[i] = mmm_log(x[i]); break;
       case 7: y[i] = sqrt(x[i]); break;
       case 8: y[i] = x[i] / x2[i]; break;
+      case 9: y[i] = x[i] / x2[i]; break; /* the HIP side evaluates its 3-instruction constant-divisor form */
       default: return MM_ERR_INVALID_ARG;
     }
   }

@@ -23,8 +23,9 @@ SI = {"lane": 0, "target_lane": 1, "speed_index": 2, "crashed": 3, "hl_action": 
 FLOAT_TOL = 1e-5  # north_star: "within 1e-5 on float state"
 
 
-def episode_files(pattern="ep_*.npz"):
-    return sorted(glob.glob(os.path.join(GOLDEN, pattern)))
+def episode_files(pattern="*_*.npz"):
+    """ep_*: random / idle tapes from reference spawns; sc_*: scripted crash scenarios (test/cbf)."""
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern)) if os.path.basename(f)[:3] in ("ep_", "sc_"))
 
 
 def load_episode(path):
@@ -189,3 +190,24 @@ def replay(make_env, path, tol=FLOAT_TOL, check_qp=True, teacher_forcing=True, m
     err.update(mx)
     err["knife_edges"] = knife
     return err
+
+
+def free_run(make_env, path):
+    """Run a tape's action script free-running (no teacher forcing) and return (steps, crashed, min headway)."""
+    z, meta = load_episode(path)
+    n = meta["n"]
+    kw = env_kwargs(meta)
+    kw["trace"] = False
+    env = make_env(E=1, N=n, **kw)
+    f0 = z["init_f"]
+    env.set_kinematics(f0[None, :, 0], f0[None, :, 1], f0[None, :, 2], f0[None, :, 3], n_merge=np.array([meta["n_merge"]]))
+    steps, done, mh = 0, False, float("inf")
+    while not done and steps < 100:
+        a = torch.tensor(z["actions"][min(steps, len(z["actions"]) - 1)][None], dtype=torch.int32, device=env.device)
+        _, _, d, out = env.step(a)
+        done = bool(d[0])
+        mh = min(mh, float(out["min_headway"][0]))
+        steps += 1
+    crashed = bool(out["crashed"].any())
+    env.close()
+    return steps, crashed, mh

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import oracle_env
-from golden_util import episode_files, replay, FLOAT_TOL
+from golden_util import episode_files, free_run, load_episode, replay, FLOAT_TOL
 from marl_mass_amd import VecMergeEnv, _cabi as abi
 
 pytestmark = pytest.mark.gpu
@@ -31,8 +31,13 @@ def test_math_bits_cpu_vs_gpu():
     ranges = {0: (-8, 8), 1: (-8, 8), 2: (-1.2, 1.2), 3: (-4, 4), 4: (-1, 1), 5: (-20, 0.5), 6: (1e-6, 100),
               7: (0, 1e6), 8: (-1e3, 1e3)}
     x2 = (torch.rand(n, dtype=torch.float64, generator=g) * 50 + 0.01)
+    # fn 9: the constant-divisor division of the kernels vs true division, on the divisors in use
+    consts = torch.tensor([300.0, 24.0, 90.0, 3.141592653589793, 2.5, 1000.0, 20.0, 1 / 15], dtype=torch.float64)
+    ranges[9] = (-2e3, 2e3)
     for fn, (lo, hi) in ranges.items():
         x = (lo + (hi - lo) * u).contiguous()
+        if fn == 9:
+            x2 = consts[torch.arange(n) % len(consts)].contiguous()
         yc = torch.zeros(n, dtype=torch.float64)
         assert olib.lib.mm_math_eval(fn, n, x.data_ptr(), x2.data_ptr(), yc.data_ptr(), None) == 0
         xg, x2g, yg = x.cuda(), x2.cuda(), torch.zeros(n, dtype=torch.float64, device="cuda:0")
@@ -49,6 +54,16 @@ def _gpu_env(E, N, **kw):
 def test_golden_tape(path):
     err = replay(_gpu_env, path, tol=1e-9, max_knife_edges=6)
     print(os.path.basename(path), json.dumps({k: float("%.3g" % v) for k, v in err.items()}))
+
+
+@pytest.mark.parametrize("path", episode_files("sc_*.npz"), ids=lambda p: os.path.basename(p)[:-4])
+def test_crash_scenarios_free_running(path):
+    """test/cbf crash scenarios on the GPU, free-running: crash step / no-crash as in the reference."""
+    _, meta = load_episode(path)
+    steps, crashed, mh = free_run(_gpu_env, path)
+    assert (steps, crashed) == (meta["steps"], meta["crashed"])
+    if meta["shield"] != "none":
+        assert mh > 0.0
 
 
 CASES = [

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_env
-from golden_util import GOLDEN, episode_files, replay
+from golden_util import GOLDEN, episode_files, free_run, load_episode, replay
 
 
 @pytest.fixture(scope="module")
@@ -112,3 +112,18 @@ def test_portable_math_accuracy(lib):
         r = ref(x)
         ulp = np.spacing(np.abs(r))
         assert float(np.max(np.abs(y - r) / ulp)) <= 4.0, fn
+
+
+@pytest.mark.parametrize("path", episode_files("sc_*.npz"), ids=lambda p: os.path.basename(p)[:-4])
+def test_crash_scenarios_free_running(path):
+    """The test/cbf crash scenarios as real assertions (the reference only eyeballs them): without
+    teacher forcing the unshielded run crashes at the reference's step, the shielded ones never do
+    and keep a positive time headway for all 100 steps."""
+    _, meta = load_episode(path)
+    oracle_env.set_math_mode(0)
+    steps, crashed, mh = free_run(oracle_env.OracleEnv, path)
+    assert (steps, crashed) == (meta["steps"], meta["crashed"])
+    if meta["shield"] != "none":
+        assert not crashed and steps == 100 and mh > 0.0
+    else:
+        assert crashed and steps < 100

@@ -98,11 +98,28 @@ def make_env(env_id, shield, n_cav, headway_time, eta):
     return env
 
 
+def _place_vehicles(env, placement):
+    """Replace the spawned vehicles by a scripted scenario: [(x, y, speed), ...] in creation order
+    (the way test/cbf/cbf_test_env.py:126-160,240-268 builds its fixed scenarios)."""
+    road = env.road
+    road.vehicles, env.controlled_vehicles = [], []
+    for k, (x, y, speed) in enumerate(placement):
+        v = env._make_ego_vehicle(road=road, position=np.array([x, y], dtype=float), speed=speed, veh_id=k)
+        env.controlled_vehicles.append(v)
+        road.vehicles.append(v)
+    env._record_vehicle_count(n_merge=sum(1 for (_, y, _) in placement if y > 5))
+    env.define_spaces()
+    obs = env.observation_type.observe()
+    return np.asarray(obs).reshape((len(obs), -1))
+
+
 def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta, p=None,
-                max_steps=100, scripted=None):
+                max_steps=100, scripted=None, placement=None):
     global _SUBSTEP_LOG
     env = make_env(env_id, shield, n_cav, headway_time, eta)
     obs0, mask0 = env.reset(is_training=False, testing_seeds=seed)
+    if placement is not None:
+        obs0 = _place_vehicles(env, placement)
     n = len(env.controlled_vehicles)
     assert n == n_cav and len(env.road.vehicles) == n_cav
     init_f, init_i = zip(*[_veh_snapshot(v) for v in env.road.vehicles])
@@ -335,6 +352,22 @@ def main():
     metas.append(run_episode("ep_v1_mass_N11_s100", v1, "cbf-cav", 11, 100, 9, 0.5, 0.03125))
     # a different eta / tau pair (eta_binary_search.sh:3-8 sweeps eta)
     metas.append(run_episode("ep_v1_mass_N4_eta05_s125", v1, "cbf-cav", 4, 125, 3, 1.2, 0.5))
+    # (3) scripted crash scenarios of test/cbf (cbf_test_env.py:26-27,163-176,203-206,277-335), placed
+    # on the merge map: a faster follower closing on a slower leader, the "extreme" speed pair, and a
+    # ramp vehicle forcing its lane change into a main-road platoon.  Unshielded they crash; the
+    # shields must not.
+    A = {"LEFT": 0, "IDLE": 1, "RIGHT": 2, "FASTER": 3, "SLOWER": 4}
+    scen = {
+        "lon": ([(25, 0.0, 25), (65, 0.0, 20)], [(A["FASTER"], A["IDLE"])]),
+        "lonx": ([(25, 0.0, 30), (65, 0.0, 15)], [(A["FASTER"], A["IDLE"])]),
+        "lon3": ([(25, 0.0, 25), (65, 0.0, 25), (105, 0.0, 20)], [(A["FASTER"], A["FASTER"], A["SLOWER"])]),
+        "merge": ([(170, 0.0, 25), (135, 0.0, 27), (172, 10.5, 25), (140, 10.5, 26)],
+                  [(A["IDLE"], A["FASTER"], A["LEFT"], A["LEFT"])]),
+    }
+    for sname, (placement, script) in scen.items():
+        for tag, shield in (("none", "none"), ("hss", "cbf-avs_cint"), ("mass", "cbf-cav")):
+            metas.append(run_episode("sc_%s_%s" % (sname, tag), v1, shield, len(placement), 0, 0, 0.5, 0.03125,
+                                     scripted=script, placement=placement))
     with open(os.path.join(OUT, "index.json"), "w") as fh:
         json.dump(metas, fh, indent=1)
 
