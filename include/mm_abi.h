@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 2
+#define MM_ABI_VERSION 3
 #define MM_MAX_AGENTS 16 /* vehicles per env (reference draws 2..11, merge_env_v1.py:180-211) */
 #define MM_N_ACTIONS 5   /* DiscreteMetaAction.ACTIONS_ALL, envs/common/action.py:141-147 */
 #define MM_OBS_ROWS 5    /* KinematicObservation vehicles_count, envs/common/observation.py:132 */
@@ -79,7 +79,10 @@ enum {
   MM_B_HL_ACTION,   /* MDPLCVehicle.hl_action (0..4), 255=None  safe_controller.py:48,65 */
   MM_B_FLAGS,       /* bit0 collaborate_adj, bit1 is_lc_safe, bit2 is_collaborating (:50,60,61) */
   MM_B_HIST_LEN,    /* min(len(state_hist), 2); >=1 also means fg_params is set (:232-239) */
-  MM_B_KIND,        /* 0 absent, 1 controlled CAV (HDVs: reserved 2) */
+  MM_B_KIND,        /* 0 absent, 1 controlled CAV, 2 HDV (IDMVehicle / IDMVehicleHist, behavior.py).
+                       Vehicles of an env are a prefix: CAVs first, then HDVs (creation order).
+                       For an HDV the SAFE_STEER / SAFE_ACC planes persist its last IDM action and
+                       G_VX its MOBIL timer (it has no safe_action / fg_params). */
   MM_B_COUNT
 };
 #define MM_FLAG_COLLABORATE_ADJ 1u
@@ -129,6 +132,9 @@ typedef struct MMConfig {
   double cbf_eta;               /* CBFType.GAMMA_B (cbf_eta in the .ini) */
   double cbf_tau;               /* CBFType.TAU     (HEADWAY_TIME in the .ini) */
   uint64_t seed;                /* base seed of the device RNG; env e uses seed + e unless seeds given */
+  int32_t n_hdv;                /* device reset: the last n_hdv of the N vehicles are IDM/MOBIL HDVs
+                                   (mixed traffic, merge_env_v1.py:298-362); 0 = CAV-only */
+  int32_t reserved1;
 } MMConfig;
 
 /*

@@ -7,7 +7,7 @@ shared object is loaded is decided by the caller, never silently.
 import ctypes as C
 import os
 
-MM_ABI_VERSION = 2
+MM_ABI_VERSION = 3
 MM_MAX_AGENTS = 16
 ENV_V0, ENV_V1 = 0, 1
 SHIELD_NONE, SHIELD_HSS, SHIELD_MASS = 0, 1, 2
@@ -49,7 +49,7 @@ class MMConfig(C.Structure):
                 ("headway_cost", C.c_double), ("headway_time", C.c_double),
                 ("merging_lane_cost", C.c_double), ("reward_speed_lo", C.c_double),
                 ("reward_speed_hi", C.c_double), ("cbf_eta", C.c_double), ("cbf_tau", C.c_double),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("n_hdv", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class MMStepOut(C.Structure):
@@ -91,7 +91,8 @@ def default_env_config(env_id):
     return cfg
 
 
-def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0, debug_flags=0):
+def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0, debug_flags=0,
+                n_hdv=0):
     """env.config dict (+ CBFType.GAMMA_B / CBFType.TAU, run_mappo.py:138-139) -> MMConfig."""
     c = MMConfig()
     c.abi_version = MM_ABI_VERSION
@@ -116,6 +117,7 @@ def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs
     c.cbf_eta = float(cbf_eta)
     c.cbf_tau = float(config["HEADWAY_TIME"] if cbf_tau is None else cbf_tau)
     c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    c.n_hdv = int(n_hdv)
     return c
 
 

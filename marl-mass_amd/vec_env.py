@@ -31,7 +31,7 @@ class BatchedMergeEnv(object):
 
     def __init__(self, clib, E, N, env_id="merge-multi-agent-v1", config=None, device="cpu",
                  cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0, first_env=0,
-                 trace=False, debug_flags=0):
+                 trace=False, debug_flags=0, n_hdv=0):
         self.clib, self.E, self.N = clib, int(E), int(N)
         self.env_id = env_id
         self.device = torch.device(device)
@@ -41,6 +41,7 @@ class BatchedMergeEnv(object):
         self.cbf_eta, self.cbf_tau = cbf_eta, cbf_tau
         self.auto_reset, self.obs_f64, self.seed = auto_reset, obs_f64, seed
         self.debug_flags = debug_flags
+        self.n_hdv = int(n_hdv)  # device reset: the last n_hdv vehicles of every env are IDM/MOBIL HDVs
         self.n_f = 6 if env_id == "merge-multi-agent-v1" else 5
         self.n_s = 5 * self.n_f  # merge_env_v1.py:28 / :413
         self._cfg = self._make_cfg()
@@ -88,7 +89,7 @@ class BatchedMergeEnv(object):
     def _make_cfg(self):
         return abi.make_config(self.env_id, self.config, cbf_eta=self.cbf_eta, cbf_tau=self.cbf_tau,
                                auto_reset=self.auto_reset, obs_f64=self.obs_f64, seed=self.seed,
-                               debug_flags=self.debug_flags)
+                               debug_flags=self.debug_flags, n_hdv=self.n_hdv)
 
     def configure(self, config=None, **kw):
         """env.config[k] = v after construction (run_mappo.py:145-171); CBFType globals via kw."""
@@ -117,8 +118,9 @@ class BatchedMergeEnv(object):
                                                _ptr(self.avail), self._stream()), self._h)
         return self.obs, self.avail
 
-    def set_kinematics(self, x, y, heading, speed, n_merge=None, env_mask=None):
-        """Host-provided spawn (numpy-compatible reset, fixtures): [E,N] tensors; NaN x = absent."""
+    def set_kinematics(self, x, y, heading, speed, n_merge=None, env_mask=None, kind=None):
+        """Host-provided spawn (numpy-compatible reset, fixtures): [E,N] tensors; NaN x = absent.
+        kind: optional [E,N] with 1 = controlled CAV, 2 = HDV (CAVs first)."""
         dev = self.device
         x = torch.as_tensor(x, dtype=torch.float64, device=dev).view(self.E, self.N)
         present = ~torch.isnan(x)
@@ -128,7 +130,10 @@ class BatchedMergeEnv(object):
         put(self.f64[abi.F["Y"]], torch.as_tensor(y, dtype=torch.float64, device=dev).view(self.E, self.N))
         put(self.f64[abi.F["HEADING"]], torch.as_tensor(heading, dtype=torch.float64, device=dev).view(self.E, self.N))
         put(self.f64[abi.F["SPEED"]], torch.as_tensor(speed, dtype=torch.float64, device=dev).view(self.E, self.N))
-        put(self.u8[abi.B["KIND"]], present.to(torch.uint8))
+        k8 = present.to(torch.uint8)
+        if kind is not None:
+            k8 = k8 * torch.as_tensor(kind, device=dev).view(self.E, self.N).to(torch.uint8)
+        put(self.u8[abi.B["KIND"]], k8)
         m = None if env_mask is None else env_mask.to(dev, torch.uint8).contiguous()
         self.clib.check(self.clib.lib.mm_init_from_kinematics(self._h, _ptr(m), self._stream()), self._h)
         if n_merge is not None:

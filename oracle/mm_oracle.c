@@ -39,14 +39,16 @@
 #include "../include/mm_math.h"
 static double pow2_libm(double x) { return pow(x, 2); }
 static double pow2_mul(double x) { return x * x; }
+static double pow4_libm(double x) { return pow(x, 4.0); }
+static double pow4_mul(double x) { double y = x * x; return y * y; }
 static double (*m_sin)(double) = sin, (*m_cos)(double) = cos, (*m_tan)(double) = tan;
 static double (*m_atan)(double) = atan, (*m_asin)(double) = asin, (*m_exp)(double) = exp;
-static double (*m_log)(double) = log, (*m_sq)(double) = pow2_libm;
+static double (*m_log)(double) = log, (*m_sq)(double) = pow2_libm, (*m_p4)(double) = pow4_libm;
 static int g_math_mode = 0;
 int32_t orc_set_math(int32_t mode) {
   g_math_mode = mode;
-  if (mode == 0) { m_sin = sin; m_cos = cos; m_tan = tan; m_atan = atan; m_asin = asin; m_exp = exp; m_log = log; m_sq = pow2_libm; }
-  else { m_sin = mmm_sin; m_cos = mmm_cos; m_tan = mmm_tan; m_atan = mmm_atan; m_asin = mmm_asin; m_exp = mmm_exp; m_log = mmm_log; m_sq = pow2_mul; }
+  if (mode == 0) { m_sin = sin; m_cos = cos; m_tan = tan; m_atan = atan; m_asin = asin; m_exp = exp; m_log = log; m_sq = pow2_libm; m_p4 = pow4_libm; }
+  else { m_sin = mmm_sin; m_cos = mmm_cos; m_tan = mmm_tan; m_atan = mmm_atan; m_asin = mmm_asin; m_exp = mmm_exp; m_log = mmm_log; m_sq = pow2_mul; m_p4 = pow4_mul; }
   return g_math_mode;
 }
 
@@ -84,14 +86,16 @@ typedef struct {
   double safe_steer, safe_acc; /* self.safe_action */
   double g_vx;                 /* fg_params["g"]["vx"] */
   double h1[2], h2[2];         /* state_hist[-1], [-2]: x, vx (all the shield reads of a record) */
-  int lane, target_lane, speed_index, crashed, hl_action, flags, hist_len, kind;
+  int lane, target_lane, speed_index, crashed, hl_action, flags, hist_len, kind; /* kind: 1 CAV, 2 HDV */
+  double timer;                /* IDMVehicle.timer (behavior.py:53) */
   double local_reward, regional_reward;
   /* trace of the last shield call */
   double qp_rows, qp_a, qp_h[4], qp_d, lc_margin;
 } Veh;
 
 typedef struct {
-  int n;
+  int n;      /* vehicles on the road (road.vehicles, creation order: CAVs first) */
+  int n_ctrl; /* controlled vehicles = the leading kind-1 entries */
   Veh v[MM_MAX_AGENTS];
   int steps, time, n_merge, episode;
 } Env;
@@ -310,6 +314,118 @@ static void get_corner(const Veh *v, int dir, double *cx, double *cy) {
   else *cy = v->y - (CORNER_LEN * m_sin(-CORNER_ALPHA + v->heading)) + 0.01;
 }
 
+
+/* ------------------------------------------------------------------ vehicle/behavior.py (HDVs) */
+#define IDM_ACC_MAX 6.0          /* behavior.py:24 */
+#define IDM_COMFORT_ACC_MAX 3.0  /* :26 */
+#define IDM_COMFORT_ACC_MIN (-5.0)
+#define IDM_DISTANCE_WANTED (5.0 + VEH_LENGTH)
+#define IDM_TIME_WANTED 1.5
+#define MOBIL_MIN_ACC_GAIN 0.1
+#define MOBIL_MAX_BRAKING 9.0
+#define MOBIL_DELAY 1.0
+
+typedef struct { int present; int is_object; double x, y, heading, speed, target_speed; int lane; } Body;
+
+static Body body_of(const Veh *v) {
+  Body b = {1, 0, v->x, v->y, v->heading, v->speed, v->target_speed, v->lane};
+  return b;
+}
+static Body body_obstacle(void) {
+  Body b = {1, 1, OBST_X, OBST_Y, 0.0, 0.0, 0.0, -1};
+  return b;
+}
+/* road.py:352-381 neighbour_vehicles on `lane`: front / rear among vehicles then objects */
+static void neighbour_vehicles(const Env *e, int i, int lane, Body *front, Body *rear) {
+  double s, r, s_front = 0, s_rear = 0;
+  lane_local(lane, e->v[i].x, e->v[i].y, &s, &r);
+  front->present = rear->present = 0;
+  for (int j = 0; j <= e->n; j++) {
+    Body b;
+    if (j < e->n) { if (j == i) continue; b = body_of(&e->v[j]); }
+    else b = body_obstacle();
+    double s_v, lat_v;
+    lane_local(lane, b.x, b.y, &s_v, &lat_v);
+    /* lane.on_lane(position, s_v, lat_v, margin=1), lane.py:61-76 */
+    if (!(fabs(lat_v) <= LANE_WIDTH / 2 + 1 && (-VEH_LENGTH <= s_v && s_v < LANE_LEN[lane] + VEH_LENGTH))) continue;
+    if (s <= s_v && (!front->present || s_v <= s_front)) { s_front = s_v; *front = b; }
+    if (s_v < s && (!rear->present || s_v > s_rear)) { s_rear = s_v; *rear = b; }
+  }
+}
+/* behavior.py:141-156 desired_gap (projected) */
+static double desired_gap(const Body *ego, const Body *front) {
+  const double ab = -IDM_COMFORT_ACC_MAX * IDM_COMFORT_ACC_MIN;
+  double ec = m_cos(ego->heading), es = m_sin(ego->heading);
+  double evx = ego->speed * ec, evy = ego->speed * es;
+  double fvx = front->speed * m_cos(front->heading), fvy = front->speed * m_sin(front->heading);
+  double dv = (evx - fvx) * ec + (evy - fvy) * es;
+  return IDM_DISTANCE_WANTED + ego->speed * IDM_TIME_WANTED + ego->speed * dv / (2 * sqrt(ab));
+}
+/* behavior.py:111-139 acceleration (IDM); ego / front may be absent, ego may be an object */
+static double idm_acceleration(const Body *ego, const Body *front) {
+  if (!ego->present || ego->is_object) return 0;
+  double ego_target_speed = not_zero(ego->target_speed);
+  double acceleration = IDM_COMFORT_ACC_MAX * (1 - m_p4(fmax(ego->speed, 0) / ego_target_speed));
+  if (front->present) {
+    double d = (front->x - LANE_SX[ego->lane]) - (ego->x - LANE_SX[ego->lane]); /* ego.lane_distance_to(front) */
+    acceleration -= IDM_COMFORT_ACC_MAX * m_sq(desired_gap(ego, front) / not_zero(d));
+  }
+  return acceleration;
+}
+/* behavior.py:225-266 mobil (no route; POLITENESS = 0 removes the followers' terms) */
+static int mobil(const Env *e, int i, int lane_index) {
+  Body self = body_of(&e->v[i]), new_prec, new_foll, old_prec, old_foll;
+  neighbour_vehicles(e, i, lane_index, &new_prec, &new_foll);
+  double new_following_pred_a = idm_acceleration(&new_foll, &self);
+  if (new_following_pred_a < -MOBIL_MAX_BRAKING) return 0;
+  neighbour_vehicles(e, i, e->v[i].lane, &old_prec, &old_foll);
+  double self_pred_a = idm_acceleration(&self, &new_prec);
+  double self_a = idm_acceleration(&self, &old_prec);
+  double jerk = self_pred_a - self_a + 0.0;
+  if (jerk < MOBIL_MIN_ACC_GAIN) return 0;
+  return 1;
+}
+/* behavior.py:183-223 change_lane_policy */
+static void change_lane_policy(Env *e, int i) {
+  Veh *v = &e->v[i];
+  if (v->lane != v->target_lane) {
+    if (lane_road(v->lane) == lane_road(v->target_lane)) {
+      Body self = body_of(v);
+      for (int j = 0; j < e->n; j++) {
+        const Veh *o = &e->v[j];
+        if (j != i && o->lane != v->target_lane && o->target_lane == v->target_lane) {
+          double d = (o->x - LANE_SX[v->lane]) - (v->x - LANE_SX[v->lane]);
+          Body ob = body_of(o);
+          double d_star = desired_gap(&self, &ob);
+          if (0 < d && d < d_star) { v->target_lane = v->lane; break; }
+        }
+      }
+    }
+    return;
+  }
+  if (!(MOBIL_DELAY < v->timer)) return; /* utils.do_every */
+  v->timer = 0;
+  /* side_lanes (road.py:147-158): only road (b,c) has two lanes */
+  int side = v->lane == MM_LANE_BC0 ? MM_LANE_BC1 : (v->lane == MM_LANE_BC1 ? MM_LANE_BC0 : -1);
+  if (side < 0) return;
+  if (!lane_is_reachable_from(side, v->x, v->y)) return;
+  if (mobil(e, i, side)) v->target_lane = side;
+}
+/* behavior.py:74-100 IDMVehicle.act */
+static void idm_act(Env *e, int i) {
+  Veh *v = &e->v[i];
+  if (v->crashed) return;
+  Body front, rear, self;
+  neighbour_vehicles(e, i, v->lane, &front, &rear);
+  follow_road(v);
+  change_lane_policy(e, i);
+  double steer = clipd(steering_control(v, v->target_lane), -PI / 3, PI / 3);
+  self = body_of(v);
+  double acc = clipd(idm_acceleration(&self, &front), -IDM_ACC_MAX, IDM_ACC_MAX);
+  v->act_steer = steer;
+  v->act_acc = acc;
+}
+
 /* ------------------------------------------------------------------ safety/decentral_layer.py */
 
 /* decentral_layer.py:15-20 */
@@ -408,7 +524,7 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
   int near[MM_MAX_AGENTS];
   int m = close_vehicles_to(e, i, PERCEPTION_DIST, 5, near);
   for (int k = 0; k < m; k++) {
-    const Veh *o = &e->v[near[k]];
+    Veh *o = &e->v[near[k]];
     int v_a = is_adj_lane(veh, o->lane);
     int a_v = is_adj_lane(o, veh->lane);
     int appr = is_approaching_same_lane(veh, o);
@@ -422,7 +538,8 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
         s_oa.present = 1; /* veh.state_hist[-2] */
         s_oa.x = o->h2[0]; s_oa.vx = o->h2[1]; /* heading / speed only feed the unused dpsi term */
         if (mass) {
-          a_oa_acc = o->safe_acc; a_oa_steer = o->safe_steer; gp_oa = o->g_vx;
+          if (o->kind == 1) { a_oa_acc = o->safe_acc; a_oa_steer = o->safe_steer; gp_oa = o->g_vx; }
+          else { a_oa_acc = CBF_ACC_LO; a_oa_steer = 0; gp_oa = 1; } /* HDV: no safe_action / fg_params (:129-135) */
           /* :138-160: the corner test always overrides the collaborate_adj expression */
           double cx, cy;
           if (v_a == -1 || a_v == 1) get_corner(o, 0, &cx, &cy);
@@ -430,10 +547,21 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
           constrain_adj = !lane_on_lane(o->lane, cx, cy);
         }
       }
+    } else if (o->kind == 2 && veh->lane == MM_LANE_AB0 && o->lane == MM_LANE_KB0 && ld >= 0) {
+      /* :162-184 adjacent HDV on the merging lane: constrain against its "digital twin" half a second
+       * of ego travel ahead.  The reference edits the HDV's history record IN PLACE, so later egos of
+       * the same sub-step read the shifted x as well -- reproduced by writing o->h2[0]. */
+      o->h2[0] = o->h2[0] + 0.5 * (veh->speed * m_cos(veh->heading));
+      s_oa.present = 1; s_oa.x = o->h2[0]; s_oa.vx = o->h2[1];
+      constrain_adj = 1;
+      a_oa_acc = CBF_ACC_LO; a_oa_steer = 0; gp_oa = 1;
     } else if (!s_ol.present && (is_same_lane(veh, o->lane) || appr) && ld > 0) {
       s_ol.present = 1;
       s_ol.x = o->h2[0]; s_ol.vx = o->h2[1];
-      if (mass) { a_ol_acc = o->safe_acc; a_ol_steer = o->safe_steer; gp_ol = o->g_vx; }
+      if (mass) {
+        if (o->kind == 1) { a_ol_acc = o->safe_acc; a_ol_steer = o->safe_steer; gp_ol = o->g_vx; }
+        else { a_ol_acc = CBF_ACC_LO; a_ol_steer = 0; gp_ol = 1; }
+      }
     }
   }
   /* obstacles (:213-246): one Obstacle at (420, 4) */
@@ -487,7 +615,7 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
   double q_lon = -VEH_LENGTH - sd0;
   double q_lona = -VEH_LENGTH - sd1;
   double q_lonr = -VEH_LENGTH - sd2;
-  if (mass && constrain_adj) q_lona = -VEH_LENGTH - sd1 - ADJ_BUFFER; /* cbf.py:380-384 */
+  if (mass && constrain_adj) q_lona = -VEH_LENGTH - sd1 - ADJ_BUFFER; /* cbf.py:380-384 (CBF_CAV only) */
   double a = g[0]; /* G[0] = [g_e.vx*dt, 0, -1] */
   double px_lon = x[2] - x[0], px_lona = x[4] - x[0], px_lonr = x[0] - x[6];
   double h0 = px_lon + (eta - 1) * px_lon + eta * q_lon + (-(g[0] * u[0]) + g[2] * u[2]);
@@ -570,8 +698,10 @@ static void clip_actions(Veh *v, int is_lc) {
 /* kinematics.py:122-141 Vehicle.step / safe_controller.py:106-185 MDPLCVehicle.step ("steer") */
 static int vehicle_step(const MMConfig *cfg, Env *e, int i, double dt) {
   Veh *v = &e->v[i];
-  const int is_lc = cfg->env_kind == MM_ENV_V1;
+  const int hdv = v->kind == 2;
+  const int is_lc = cfg->env_kind == MM_ENV_V1 && !hdv; /* MDPLCVehicle; HDVs use Vehicle.step */
   int rc = 0;
+  if (hdv) v->timer += dt; /* IDMVehicle.step behavior.py:102-109 */
   clip_actions(v, is_lc);
   double steer = v->act_steer, acc = v->act_acc;
   v->qp_rows = 0; v->qp_a = NAN; v->qp_d = NAN; v->lc_margin = NAN;
@@ -589,7 +719,7 @@ static int vehicle_step(const MMConfig *cfg, Env *e, int i, double dt) {
   v->speed = v->speed > 0 ? v->speed : 0; /* max(0, speed) */
   if (is_lc) v->g_vx = m_cos(v->heading + beta);
   v->lane = closest_lane(v->x, v->y, v->heading); /* on_state_update kinematics.py:154-159 */
-  if (is_lc) { /* log_step: state_hist.append(to_dict()) safe_controller.py:187-201 */
+  if (is_lc || (hdv && cfg->env_kind == MM_ENV_V1)) { /* log_step safe_controller.py:187-201 / behavior.py:505-521 (IDMVehicleHist) */
     memcpy(v->h2, v->h1, sizeof v->h1);
     v->h1[0] = v->x; v->h1[1] = v->speed * m_cos(v->heading);
     if (v->hist_len < 2) v->hist_len++;
@@ -617,7 +747,7 @@ static void sort_by_x_desc(const Env *e, int *order) { /* sorted(key=x, reverse=
 /* merge_env_v1.py:168-172 */
 static int is_terminal(const MMConfig *cfg, const Env *e) {
   int any_crashed = 0, any_neg = 0;
-  for (int i = 0; i < e->n; i++) { any_crashed |= e->v[i].crashed; any_neg |= e->v[i].x < 0; }
+  for (int i = 0; i < e->n_ctrl; i++) { any_crashed |= e->v[i].crashed; any_neg |= e->v[i].x < 0; }
   return any_crashed || e->steps >= cfg->duration * cfg->policy_frequency || any_neg;
 }
 
@@ -630,9 +760,12 @@ static int simulate(const MMConfig *cfg, Env *e, const int32_t *actions, double 
   int rc = 0, order[MM_MAX_AGENTS];
   for (int k = 0; k < nsub; k++) {
     if (e->time % nsub == 0) /* action_type.act(action): action.py:226-231 */
-      for (int i = 0; i < e->n; i++) mdp_act(&e->v[i], actions[i], is_lc);
-    sort_by_x_desc(e, order); /* road.act */
-    for (int r = 0; r < e->n; r++) mdp_act(&e->v[order[r]], -1, is_lc);
+      for (int i = 0; i < e->n_ctrl; i++) mdp_act(&e->v[i], actions[i], is_lc);
+    sort_by_x_desc(e, order); /* road.act: front to back; HDVs read what earlier vehicles already decided */
+    for (int r = 0; r < e->n; r++) {
+      if (e->v[order[r]].kind == 2) idm_act(e, order[r]);
+      else mdp_act(&e->v[order[r]], -1, is_lc);
+    }
     sort_by_x_desc(e, order); /* road.step */
     for (int r = 0; r < e->n; r++) {
       int rr = vehicle_step(cfg, e, order[r], dt);
@@ -662,8 +795,8 @@ static int simulate(const MMConfig *cfg, Env *e, const int32_t *actions, double 
         t[MM_T_X * A] = v->x; t[MM_T_Y * A] = v->y; t[MM_T_HEADING * A] = v->heading;
         t[MM_T_SPEED * A] = v->speed; t[MM_T_ACT_STEER * A] = v->act_steer;
         t[MM_T_ACT_ACC * A] = v->act_acc;
-        t[MM_T_SAFE_STEER * A] = is_lc ? v->safe_steer : v->act_steer;
-        t[MM_T_SAFE_ACC * A] = is_lc ? v->safe_acc : v->act_acc;
+        t[MM_T_SAFE_STEER * A] = (is_lc && v->kind == 1) ? v->safe_steer : v->act_steer;
+        t[MM_T_SAFE_ACC * A] = (is_lc && v->kind == 1) ? v->safe_acc : v->act_acc;
         t[MM_T_LANE * A] = v->lane; t[MM_T_TARGET_LANE * A] = v->target_lane;
         t[MM_T_CRASHED * A] = v->crashed; t[MM_T_FLAGS * A] = v->flags;
         t[MM_T_QP_ROWS * A] = v->qp_rows; t[MM_T_QP_A * A] = v->qp_a;
@@ -713,7 +846,7 @@ static void action_mask(const MMConfig *cfg, const Env *e, uint8_t *out /* [n][5
   uint8_t m[5] = {1, 1, 1, 1, 1};
   if (cfg->action_masking) {
     memset(m, 0, 5);
-    for (int i = 0; i < e->n; i++) {
+    for (int i = 0; i < e->n_ctrl; i++) {
       const Veh *v = &e->v[i];
       m[1] = 1;
       if (v->lane == MM_LANE_BC1 && lane_is_reachable_from(MM_LANE_BC0, v->x, v->y)) m[0] = 1;
@@ -722,7 +855,7 @@ static void action_mask(const MMConfig *cfg, const Env *e, uint8_t *out /* [n][5
       if (v->speed_index > 0) m[4] = 1;
     }
   }
-  for (int i = 0; i < e->n; i++) memcpy(out + 5 * i, m, 5);
+  for (int i = 0; i < e->n_ctrl; i++) memcpy(out + 5 * i, m, 5);
 }
 
 /* ------------------------------------------------------------------ rewards / info */
@@ -778,7 +911,7 @@ static void surrounding_vehicles(const Env *e, int i, int lane_index, int *front
 }
 /* merge_env_v1.py:91-124 */
 static void regional_reward(Env *e) {
-  for (int i = 0; i < e->n; i++) {
+  for (int i = 0; i < e->n_ctrl; i++) {
     Veh *v = &e->v[i];
     int fl = -1, rl = -1, fr = -1, rr = -1;
     if (v->lane == MM_LANE_AB0 || v->lane == MM_LANE_BC0 || v->lane == MM_LANE_CD0) {
@@ -793,14 +926,14 @@ static void regional_reward(Env *e) {
     int list[5] = {fl, fr, i, rl, rr};
     double sum = 0; int cnt = 0;
     for (int k = 0; k < 5; k++)
-      if (list[k] >= 0) { sum += e->v[list[k]].local_reward; cnt++; }
+      if (list[k] >= 0 && e->v[list[k]].kind == 1) { sum += e->v[list[k]].local_reward; cnt++; } /* isinstance(v, MDPVehicle) */
     v->regional_reward = sum / cnt;
   }
 }
 /* merge_env_v1.py:373-386 */
 static double min_time_headway(const Env *e) {
   double mh = INFINITY;
-  for (int i = 0; i < e->n; i++) {
+  for (int i = 0; i < e->n_ctrl; i++) {
     const Veh *v = &e->v[i];
     double hd = compute_headway_distance(e, i);
     if (fabs(OBST_Y - v->y) <= 2 && OBST_X > v->x) {
@@ -845,39 +978,55 @@ static void init_vehicle(Veh *v) {
   v->lane = closest_lane(v->x, v->y, v->heading);
   v->target_lane = v->lane;
   v->target_speed = v->speed;
-  v->speed_index = speed_to_index(v->target_speed);
-  v->target_speed = index_to_speed(v->speed_index);
+  v->timer = 0;
+  if (v->kind == 2) { /* IDMVehicle.__init__ behavior.py:42-53: timer = (sum(position) * pi) % LANE_CHANGE_DELAY */
+    v->speed_index = 0;
+    v->timer = py_mod((v->x + v->y) * PI, MOBIL_DELAY);
+  } else {
+    v->speed_index = speed_to_index(v->target_speed);
+    v->target_speed = index_to_speed(v->speed_index);
+  }
   v->act_steer = v->act_acc = 0;
   v->safe_steer = v->safe_acc = 0;
   v->g_vx = NAN; /* fg_params = None */
   memset(v->h1, 0, sizeof v->h1);
   memset(v->h2, 0, sizeof v->h2);
-  v->crashed = 0; v->hl_action = MM_HL_NONE; v->flags = 0; v->hist_len = 0; v->kind = 1;
+  v->crashed = 0; v->hl_action = MM_HL_NONE; v->flags = 0; v->hist_len = 0;
   v->local_reward = v->regional_reward = 0;
 }
 
 /* merge_env_v1.py:265-364 _make_vehicles for N CAVs / 0 HDVs with the device RNG stream
  * (draw plan documented in DESIGN.md "Device reset"): N/2 on ab0 first, the rest on jk0. */
-static void spawn_env(Env *e, int N, uint64_t seed, uint32_t episode) {
+static void spawn_env(Env *e, int n_cav, int n_hdv, uint64_t seed, uint32_t episode) {
   int slots_s[6] = {10, 60, 110, 160, 210, 260}, slots_m[6] = {5, 55, 105, 155, 205, 255};
-  int n_s = (N != 1) ? N / 2 : (int)(rng_u32(seed, episode, 0) & 1u);
-  int n_m = N - n_s;
-  for (int i = 0; i < n_s && i < 6; i++) { /* choice(replace=False) as a partial Fisher-Yates */
+  const uint32_t coin = rng_u32(seed, episode, 0);
+  int n_s = (n_cav != 1) ? n_cav / 2 : (int)(coin & 1u);           /* CAVs on the main road */
+  int n_m = n_cav - n_s;                                            /* CAVs on the ramp */
+  int n_sh = (n_hdv != 1) ? n_hdv / 2 : (int)((coin >> 1) & 1u);    /* HDVs: remaining slots (:298-308) */
+  int n_mh = n_hdv - n_sh;
+  /* one partial Fisher-Yates per road: CAV slots first, HDV slots continue the same shuffle, so
+   * all spawn points are distinct like the reference's remove-then-choice (:287-308) */
+  for (int i = 0; i < n_s + n_sh && i < 6; i++) {
     int j = i + (int)(((uint64_t)rng_u32(seed, episode, (uint32_t)i) * (uint32_t)(6 - i)) >> 32);
     int t = slots_s[i]; slots_s[i] = slots_s[j]; slots_s[j] = t;
   }
-  for (int i = 0; i < n_m && i < 6; i++) {
+  for (int i = 0; i < n_m + n_mh && i < 6; i++) {
     int j = i + (int)(((uint64_t)rng_u32(seed, episode, (uint32_t)(6 + i)) * (uint32_t)(6 - i)) >> 32);
     int t = slots_m[i]; slots_m[i] = slots_m[j]; slots_m[j] = t;
   }
-  e->n = N;
-  for (int k = 0; k < N; k++) {
+  const int N = n_cav + n_hdv;
+  e->n = N; e->n_ctrl = n_cav;
+  for (int k = 0; k < N; k++) { /* creation order: CAV main, CAV ramp, HDV main, HDV ramp (:326-362) */
     Veh *v = &e->v[k];
+    memset(v, 0, sizeof *v);
     double speed = rng_f64(seed, episode, 12u + 4u * k) * 2 + 25;
     double noise = rng_f64(seed, episode, 12u + 4u * k + 2u) * 8 - 4;
     if (k < n_s) { v->x = slots_s[k] + noise; v->y = 0.0; }
-    else { v->x = slots_m[k - n_s] + noise; v->y = 10.5; }
+    else if (k < n_cav) { v->x = slots_m[k - n_s] + noise; v->y = 10.5; }
+    else if (k < n_cav + n_sh) { v->x = slots_s[n_s + (k - n_cav)] + noise; v->y = 0.0; }
+    else { v->x = slots_m[n_m + (k - n_cav - n_sh)] + noise; v->y = 10.5; }
     v->heading = 0; v->speed = speed;
+    v->kind = k < n_cav ? 1 : 2;
     init_vehicle(v);
   }
   e->steps = e->time = 0;
@@ -891,7 +1040,7 @@ static void load_env(const struct MMHandle_ *h, int64_t e_idx, Env *e) {
   const double *F = (const double *)(h->state + h->lay.f64_offset);
   const uint8_t *B = h->state + h->lay.u8_offset;
   const int32_t *I = (const int32_t *)(h->state + h->lay.env_offset);
-  e->n = 0;
+  e->n = 0; e->n_ctrl = 0;
   for (int a = 0; a < h->N; a++) {
     int64_t i = base + a;
     if (B[MM_B_KIND * A + i] == 0) continue;
@@ -906,6 +1055,10 @@ static void load_env(const struct MMHandle_ *h, int64_t e_idx, Env *e) {
     v->speed_index = B[MM_B_SPEED_INDEX * A + i]; v->crashed = B[MM_B_CRASHED * A + i];
     v->hl_action = B[MM_B_HL_ACTION * A + i]; v->flags = B[MM_B_FLAGS * A + i];
     v->hist_len = B[MM_B_HIST_LEN * A + i]; v->kind = B[MM_B_KIND * A + i];
+    if (v->kind == 1 && e->n_ctrl == e->n - 1) e->n_ctrl = e->n; /* controlled vehicles are a prefix */
+    if (v->kind == 2) { /* HDV: the SAFE_* planes persist its last IDM action, G_VX its MOBIL timer */
+      v->act_steer = v->safe_steer; v->act_acc = v->safe_acc; v->timer = v->g_vx;
+    }
   }
   e->steps = I[MM_E_STEPS * h->E + e_idx]; e->time = I[MM_E_TIME * h->E + e_idx];
   e->n_merge = I[MM_E_N_MERGE * h->E + e_idx]; e->episode = I[MM_E_EPISODE * h->E + e_idx];
@@ -921,8 +1074,9 @@ static void store_env(struct MMHandle_ *h, int64_t e_idx, const Env *e) {
     const Veh *v = &e->v[a];
     F[MM_F_X * A + i] = v->x; F[MM_F_Y * A + i] = v->y; F[MM_F_HEADING * A + i] = v->heading;
     F[MM_F_SPEED * A + i] = v->speed; F[MM_F_TARGET_SPEED * A + i] = v->target_speed;
-    F[MM_F_SAFE_STEER * A + i] = v->safe_steer; F[MM_F_SAFE_ACC * A + i] = v->safe_acc;
-    F[MM_F_G_VX * A + i] = v->g_vx;
+    F[MM_F_SAFE_STEER * A + i] = v->kind == 2 ? v->act_steer : v->safe_steer;
+    F[MM_F_SAFE_ACC * A + i] = v->kind == 2 ? v->act_acc : v->safe_acc;
+    F[MM_F_G_VX * A + i] = v->kind == 2 ? v->timer : v->g_vx;
     for (int k = 0; k < 2; k++) { F[(MM_F_H1_X + k) * A + i] = v->h1[k]; F[(MM_F_H2_X + k) * A + i] = v->h2[k]; }
     B[MM_B_LANE * A + i] = (uint8_t)v->lane; B[MM_B_TARGET_LANE * A + i] = (uint8_t)v->target_lane;
     B[MM_B_SPEED_INDEX * A + i] = (uint8_t)v->speed_index; B[MM_B_CRASHED * A + i] = (uint8_t)v->crashed;
@@ -937,7 +1091,7 @@ static void write_obs(const struct MMHandle_ *h, const Env *e, int64_t e_idx, vo
   const int F = h->cfg.env_kind == MM_ENV_V1 ? 6 : 5, S = 5 * F;
   double row[30];
   for (int a = 0; a < h->N; a++) {
-    if (a < e->n) observe_agent(&h->cfg, e, a, row);
+    if (a < e->n_ctrl) observe_agent(&h->cfg, e, a, row);
     else memset(row, 0, sizeof row);
     int64_t o = (e_idx * h->N + a) * S;
     if (obs) {
@@ -977,6 +1131,7 @@ static int check_cfg(const MMConfig *c, int N, char *err) {
   if (c->policy_frequency <= 0 || c->simulation_frequency < c->policy_frequency ||
       c->simulation_frequency / c->policy_frequency > 3) { snprintf(err, 256, "unsupported frequencies"); return MM_ERR_INVALID_ARG; }
   if (N > 12) { snprintf(err, 256, "N=%d exceeds the 6+6 spawn slots", N); return MM_ERR_INVALID_ARG; }
+  if (c->n_hdv < 0 || c->n_hdv >= N) { snprintf(err, 256, "n_hdv=%d must leave at least one controlled vehicle of N=%d", c->n_hdv, N); return MM_ERR_INVALID_ARG; }
   return MM_OK;
 }
 
@@ -1014,7 +1169,7 @@ int32_t mm_reset(MMHandle h, const uint8_t *env_mask, const uint64_t *seeds_in, 
     load_env(h, e_idx, &e);
     if (seeds_in) seeds[e_idx] = seeds_in[e_idx];
     int episode = e.episode;
-    spawn_env(&e, h->N, seeds[e_idx], (uint32_t)episode);
+    spawn_env(&e, h->N - h->cfg.n_hdv, h->cfg.n_hdv, seeds[e_idx], (uint32_t)episode);
     e.episode = episode + 1;
     store_env(h, e_idx, &e);
     write_obs(h, &e, e_idx, obs, avail);
@@ -1034,7 +1189,7 @@ int32_t mm_init_from_kinematics(MMHandle h, const uint8_t *env_mask, MMStream st
     int n_m = 0;
     for (int a = 0; a < e.n; a++) {
       init_vehicle(&e.v[a]);
-      if (e.v[a].lane == MM_LANE_JK0) n_m++;
+      if (a < e.n_ctrl && (e.v[a].lane == MM_LANE_JK0 || e.v[a].lane == MM_LANE_KB0)) n_m++;
     }
     (void)A; (void)B;
     e.steps = e.time = 0; e.n_merge = n_m;
@@ -1069,7 +1224,7 @@ int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStre
     Env e;
     load_env(h, e_idx, &e);
     const int64_t base = e_idx * h->N;
-    if (e.n == 0) continue;
+    if (e.n_ctrl == 0) continue;
     e.steps += 1; /* abstract.py:457 */
     int rc = simulate(cfg, &e, actions + base, out->trace, A, base);
     if (rc) {
@@ -1078,38 +1233,39 @@ int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStre
     }
     /* AbstractEnv.step abstract.py:469-498 then MergeEnv.step merge_env_v1.py:126-166 */
     int done = is_terminal(cfg, &e);
-    double rsum = 0, ssum = 0;
-    for (int i = 0; i < e.n; i++) {
+    double rsum = 0, ssum = 0, tsum = 0;
+    for (int i = 0; i < e.n_ctrl; i++) {
       e.v[i].local_reward = agent_reward(cfg, &e, i);
       rsum += e.v[i].local_reward;
       ssum += e.v[i].speed;
     }
-    double reward = rsum / e.n, avg_speed = ssum / e.n;
+    for (int i = 0; i < e.n; i++) tsum += e.v[i].speed; /* traffic_speed over road.vehicles (:147-151) */
+    double reward = rsum / e.n_ctrl, avg_speed = ssum / e.n_ctrl, traffic_speed = tsum / e.n;
     regional_reward(&e);
     double mh = min_time_headway(&e);
     double merge_pct = NAN;
     int any_crashed = 0;
-    for (int i = 0; i < e.n; i++) any_crashed |= e.v[i].crashed;
+    for (int i = 0; i < e.n_ctrl; i++) any_crashed |= e.v[i].crashed;
     if (done) {
       int n_rem = 0;
-      for (int i = 0; i < e.n; i++)
+      for (int i = 0; i < e.n_ctrl; i++)
         if (e.v[i].lane == MM_LANE_BC1 || e.v[i].lane == MM_LANE_KB0 || e.v[i].lane == MM_LANE_JK0) n_rem++;
       merge_pct = e.n_merge > 0 ? (double)(e.n_merge - n_rem) / e.n_merge * 100 : 100.0;
     }
     if (out->reward) out->reward[e_idx] = reward;
     if (out->done) out->done[e_idx] = (uint8_t)done;
     if (out->average_speed) out->average_speed[e_idx] = avg_speed;
-    if (out->traffic_speed) out->traffic_speed[e_idx] = avg_speed; /* CAV-only: road.vehicles == controlled */
+    if (out->traffic_speed) out->traffic_speed[e_idx] = traffic_speed;
     if (out->min_headway) out->min_headway[e_idx] = mh;
     if (out->merge_percent) out->merge_percent[e_idx] = merge_pct;
     const int T = cfg->duration * cfg->policy_frequency;
     for (int a = 0; a < h->N; a++) {
-      const int live = a < e.n;
+      const int live = a < e.n, ctrl = a < e.n_ctrl;
       const Veh *v = &e.v[a];
-      if (out->agents_rewards) out->agents_rewards[base + a] = live ? v->local_reward : 0;
-      if (out->regional_rewards) out->regional_rewards[base + a] = live ? v->regional_reward : 0;
-      if (out->agents_dones) /* merge_env_v1.py:174-178 */
-        out->agents_dones[base + a] = live ? (uint8_t)(v->crashed || e.steps >= T || v->x < 0) : 1;
+      if (out->agents_rewards) out->agents_rewards[base + a] = ctrl ? v->local_reward : 0;
+      if (out->regional_rewards) out->regional_rewards[base + a] = ctrl ? v->regional_reward : 0;
+      if (out->agents_dones) /* merge_env_v1.py:174-178 (controlled vehicles; other slots read 1) */
+        out->agents_dones[base + a] = ctrl ? (uint8_t)(v->crashed || e.steps >= T || v->x < 0) : 1;
       if (out->crashed) out->crashed[base + a] = live ? (uint8_t)v->crashed : 0;
       if (out->agents_info) {
         out->agents_info[(base + a) * 3 + 0] = live ? v->x : 0;
@@ -1117,12 +1273,12 @@ int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStre
         out->agents_info[(base + a) * 3 + 2] = live ? v->speed : 0;
       }
     }
-    m_sum[0] += reward; m_sum[2] += avg_speed; m_sum[3] += avg_speed; m_sum[4] += 1;
+    m_sum[0] += reward; m_sum[2] += avg_speed; m_sum[3] += traffic_speed; m_sum[4] += 1;
     if (done) { m_sum[1] += any_crashed; m_sum[5] += merge_pct; m_sum[6] += 1; }
     if (mh < m_min) m_min = mh;
     if (done && cfg->auto_reset) { /* caller-side `if done: env.reset()` (marl/mappo.py:133-135) */
       int episode = e.episode;
-      spawn_env(&e, h->N, seeds[e_idx], (uint32_t)episode);
+      spawn_env(&e, e.n_ctrl, e.n - e.n_ctrl, seeds[e_idx], (uint32_t)episode);
       e.episode = episode + 1;
     }
     store_env(h, e_idx, &e);

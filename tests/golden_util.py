@@ -16,16 +16,17 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # columns of sub_f / sub_i written by tools/gen_golden.py:_veh_snapshot
 SF = {"x": 0, "y": 1, "heading": 2, "speed": 3, "target_speed": 4, "act_steer": 5, "act_acc": 6,
-      "safe_steer": 7, "safe_acc": 8, "g_vx": 9}
+      "safe_steer": 7, "safe_acc": 8, "g_vx": 9, "timer": 10}
 SI = {"lane": 0, "target_lane": 1, "speed_index": 2, "crashed": 3, "hl_action": 4,
-      "collaborate_adj": 5, "is_lc_safe": 6, "is_collaborating": 7}
+      "collaborate_adj": 5, "is_lc_safe": 6, "is_collaborating": 7, "kind": 8}
 
 FLOAT_TOL = 1e-5  # north_star: "within 1e-5 on float state"
 
 
 def episode_files(pattern="*_*.npz"):
-    """ep_*: random / idle tapes from reference spawns; sc_*: scripted crash scenarios (test/cbf)."""
-    return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern)) if os.path.basename(f)[:3] in ("ep_", "sc_"))
+    """ep_*: random / idle tapes from reference spawns; sc_*: scripted crash scenarios (test/cbf);
+    mx_*: mixed traffic (CAVs + IDM/MOBIL HDVs)."""
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern)) if os.path.basename(f)[:3] in ("ep_", "sc_", "mx_"))
 
 
 def load_episode(path):
@@ -47,8 +48,13 @@ KNIFE_EDGE = 1e-9  # |LC margin| below this = the reference's own decision is ro
 def _force_state(env, z, meta, t, s_at):
     """Teacher forcing: load the reference's state at the start of step t (end of sub-step s_at-1)."""
     F, B, EP = abi.F, abi.B, abi.EP
-    n = meta["n"]
-    gf, gi = z["sub_f"][s_at - 1], z["sub_i"][s_at - 1]
+    n = meta["n"] + meta.get("n_hdv", 0)
+    gf, gi = z["sub_f"][s_at - 1].copy(), z["sub_i"][s_at - 1]
+    hdv = gi[:, SI["kind"]] == 2
+    # HDVs keep their last IDM action in the SAFE_* planes and the MOBIL timer in G_VX (mm_abi.h)
+    gf[hdv, SF["safe_steer"]] = gf[hdv, SF["act_steer"]]
+    gf[hdv, SF["safe_acc"]] = gf[hdv, SF["act_acc"]]
+    gf[hdv, SF["g_vx"]] = gf[hdv, SF["timer"]]
     dev = env.device
     put = lambda plane, v: plane.__setitem__(0, torch.as_tensor(np.asarray(v), device=dev).to(plane.dtype))  # noqa: E731
     for name, col in (("X", "x"), ("Y", "y"), ("HEADING", "heading"), ("SPEED", "speed"),
@@ -72,7 +78,7 @@ def _force_state(env, z, meta, t, s_at):
     put(env.u8[B["FLAGS"]], gi[:, SI["collaborate_adj"]] * abi.FLAG_COLLABORATE_ADJ
         + gi[:, SI["is_lc_safe"]] * abi.FLAG_IS_LC_SAFE + gi[:, SI["is_collaborating"]] * abi.FLAG_IS_COLLABORATING)
     put(env.u8[B["HIST_LEN"]], np.full(n, min(2, s_at)))
-    put(env.u8[B["KIND"]], np.ones(n))
+    put(env.u8[B["KIND"]], gi[:, SI["kind"]])
     env.env_i32[EP["STEPS"], 0] = t
     env.env_i32[EP["TIME"], 0] = s_at
     env.env_i32[EP["N_MERGE"], 0] = meta["n_merge"]
@@ -87,17 +93,22 @@ def replay(make_env, path, tol=FLOAT_TOL, check_qp=True, teacher_forcing=True, m
     knife-edge (|LC margin| < 1e-9, see include/mm_math.h): those steps are counted in
     err["knife_edges"] (bounded by `max_knife_edges`) and skipped."""
     z, meta = load_episode(path)
-    n = meta["n"]
+    nc = meta["n"]                    # controlled vehicles
+    n = nc + meta.get("n_hdv", 0)     # all vehicles on the road
     env = make_env(E=1, N=n, **env_kwargs(meta))
     f0, dev = z["init_f"], env.device
-    obs, _ = env.set_kinematics(f0[None, :, 0], f0[None, :, 1], f0[None, :, 2], f0[None, :, 3],
-                                n_merge=np.array([meta["n_merge"]]))
-    # derived initial state (Vehicle/MDPVehicle.__init__)
     i0 = z["init_i"]
+    kind0 = i0[:, SI["kind"]] if i0.shape[1] > SI["kind"] else np.ones(n, dtype=np.int64)
+    obs, _ = env.set_kinematics(f0[None, :, 0], f0[None, :, 1], f0[None, :, 2], f0[None, :, 3],
+                                n_merge=np.array([meta["n_merge"]]), kind=kind0[None])
+    # derived initial state (Vehicle / MDPVehicle / IDMVehicle.__init__)
     assert np.array_equal(env.u8[abi.B["LANE"], 0].cpu().numpy(), i0[:, SI["lane"]])
     assert np.array_equal(env.u8[abi.B["SPEED_INDEX"], 0].cpu().numpy(), i0[:, SI["speed_index"]])
     np.testing.assert_allclose(env.f64[abi.F["TARGET_SPEED"], 0].cpu().numpy(), f0[:, SF["target_speed"]], atol=0, rtol=0)
-    err = {"obs0": float(np.abs(obs[0].cpu().numpy() - z["obs0"]).max())}
+    if (kind0 == 2).any():
+        np.testing.assert_allclose(env.f64[abi.F["G_VX"], 0].cpu().numpy()[kind0 == 2], f0[kind0 == 2, SF["timer"]],
+                                   atol=1e-12, rtol=0)
+    err = {"obs0": float(np.abs(obs[0, :nc].cpu().numpy() - z["obs0"]).max())}
     assert err["obs0"] <= tol, err
     sub_f, sub_i, sub_count = z["sub_f"], z["sub_i"], z["sub_count"]
     qp_G, qp_h, qp_x, qp_rows = z["qp_G"], z["qp_h"], z["qp_x"], z["qp_rows"]
@@ -124,7 +135,9 @@ def replay(make_env, path, tol=FLOAT_TOL, check_qp=True, teacher_forcing=True, m
         nqp = int(z["qp_count"][t])
         if teacher_forcing and t > 0:
             _force_state(env, z, meta, t, s_at)
-        a = torch.tensor(z["actions"][t][None], dtype=torch.int32, device=dev)
+        act = np.ones((1, n), dtype=np.int32)
+        act[0, :nc] = z["actions"][t]
+        a = torch.tensor(act, dtype=torch.int32, device=dev)
         obs, rew, done, out = env.step(a)
         tr = env.trace[:, :, 0].cpu().numpy()  # [3, T, n]
         step_mx = dict(mx)
@@ -141,6 +154,7 @@ def replay(make_env, path, tol=FLOAT_TOL, check_qp=True, teacher_forcing=True, m
                     fl = tr[k, abi.T["FLAGS"]].astype(np.int64)
                     rows = tr[k, abi.T["QP_ROWS"]].astype(np.int64)
                     if rows.any():  # shield ran this sub-step: flags are defined
+                        fl = np.where(gi[:, SI["kind"]] == 1, fl, 0)
                         for bit, col in ((abi.FLAG_IS_LC_SAFE, "is_lc_safe"), (abi.FLAG_IS_COLLABORATING, "is_collaborating"),
                                          (abi.FLAG_COLLABORATE_ADJ, "collaborate_adj")):
                             discrete(np.array_equal((fl & bit) != 0, gi[:, SI[col]] != 0), tr, k, (path, t, k, col))
@@ -148,6 +162,8 @@ def replay(make_env, path, tol=FLOAT_TOL, check_qp=True, teacher_forcing=True, m
                         # the reference solves in road.step order = descending pre-step x
                         xs_prev = (sub_f[s_at + k - 1][:, SF["x"]] if (s_at + k) > 0 else f0[:, SF["x"]])
                         for j in sorted(range(n), key=lambda j: -xs_prev[j]):
+                            if gi[j, SI["kind"]] != 1:
+                                continue  # HDVs solve no QP
                             discrete(rows[j] == qp_rows[q_loc], tr, k, (path, t, k, j, rows[j], qp_rows[q_loc]))
                             got_h = np.array([tr[k, abi.T["QP_H%d" % r], j] for r in range(rows[j])])
                             e = max(abs(tr[k, abi.T["QP_A"], j] - qp_G[q_loc, 0, 0]),
@@ -163,19 +179,19 @@ def replay(make_env, path, tol=FLOAT_TOL, check_qp=True, teacher_forcing=True, m
                 for name, col in cols:
                     step_mx["action"] = max(step_mx["action"], float(np.abs(tr[k, abi.T[name]] - gf[:, SF[col]]).max()))
             o = {k2: v[0].cpu().numpy() for k2, v in out.items()}
-            step_mx["obs"] = max(step_mx["obs"], float(np.abs(obs[0].cpu().numpy() - z["obs"][t]).max()))
+            step_mx["obs"] = max(step_mx["obs"], float(np.abs(obs[0, :nc].cpu().numpy() - z["obs"][t]).max()))
             step_mx["reward"] = max(step_mx["reward"], abs(float(o["reward"]) - z["reward"][t]),
-                                    float(np.abs(o["agents_rewards"] - z["agents_rewards"][t]).max()),
-                                    float(np.abs(o["regional_rewards"] - z["regional_rewards"][t]).max()))
+                                    float(np.abs(o["agents_rewards"][:nc] - z["agents_rewards"][t]).max()),
+                                    float(np.abs(o["regional_rewards"][:nc] - z["regional_rewards"][t]).max()))
             step_mx["info"] = max(step_mx["info"], abs(float(o["average_speed"]) - z["average_speed"][t]),
                                   abs(float(o["traffic_speed"]) - z["traffic_speed"][t]),
                                   abs(float(o["min_headway"]) - z["min_headway"][t]))
             discrete(bool(o["done"]) == bool(z["done"][t]), tr, 2, (path, t, "done"))
-            discrete(np.array_equal(o["agents_dones"].astype(bool), z["agents_dones"][t]), tr, 2, (path, t, "agents_dones"))
-            discrete(np.array_equal(o["action_mask"], z["action_mask"][t]), tr, 2, (path, t, "action_mask"))
+            discrete(np.array_equal(o["agents_dones"][:nc].astype(bool), z["agents_dones"][t]), tr, 2, (path, t, "agents_dones"))
+            discrete(np.array_equal(o["action_mask"][:nc], z["action_mask"][t]), tr, 2, (path, t, "action_mask"))
             if z["done"][t]:
                 assert abs(float(o["merge_percent"]) - z["merge_percent"][t]) <= 1e-9
-                assert bool(o["crashed"].any()) == meta["crashed"]
+                assert bool(o["crashed"][:nc].any()) == meta["crashed"]
             for key, v in step_mx.items():
                 discrete(v <= tol, tr, 2, (path, t, key, v))
             mx = step_mx
@@ -195,12 +211,13 @@ def replay(make_env, path, tol=FLOAT_TOL, check_qp=True, teacher_forcing=True, m
 def free_run(make_env, path):
     """Run a tape's action script free-running (no teacher forcing) and return (steps, crashed, min headway)."""
     z, meta = load_episode(path)
-    n = meta["n"]
+    n = meta["n"] + meta.get("n_hdv", 0)
     kw = env_kwargs(meta)
     kw["trace"] = False
     env = make_env(E=1, N=n, **kw)
-    f0 = z["init_f"]
-    env.set_kinematics(f0[None, :, 0], f0[None, :, 1], f0[None, :, 2], f0[None, :, 3], n_merge=np.array([meta["n_merge"]]))
+    f0, i0 = z["init_f"], z["init_i"]
+    env.set_kinematics(f0[None, :, 0], f0[None, :, 1], f0[None, :, 2], f0[None, :, 3], n_merge=np.array([meta["n_merge"]]),
+                       kind=i0[None, :, SI["kind"]])
     steps, done, mh = 0, False, float("inf")
     while not done and steps < 100:
         a = torch.tensor(z["actions"][min(steps, len(z["actions"]) - 1)][None], dtype=torch.int32, device=env.device)

@@ -53,12 +53,14 @@ def _veh_snapshot(v):
     f = [v.position[0], v.position[1], v.heading, v.speed, v.target_speed,
          float(v.action["steering"]), float(v.action["acceleration"]),
          float(sa["steering"]), float(sa["acceleration"]),
-         float(fg["g"]["vx"]) if fg else np.nan]
-    i = [LANE_ID[tuple(v.lane_index)], LANE_ID[tuple(v.target_lane_index)], int(v.speed_index),
+         float(fg["g"]["vx"]) if fg else np.nan,
+         float(getattr(v, "timer", np.nan))]
+    i = [LANE_ID[tuple(v.lane_index)], LANE_ID[tuple(v.target_lane_index)], int(getattr(v, "speed_index", 0)),
          int(bool(v.crashed)), HL[getattr(v, "hl_action", None)],
          int(bool(getattr(v, "collaborate_adj", False))) if is_lc else 0,
          int(bool(getattr(v, "is_lc_safe", False))) if is_lc else 0,
-         int(bool(getattr(v, "is_collaborating", False))) if is_lc else 0]
+         int(bool(getattr(v, "is_collaborating", False))) if is_lc else 0,
+         1 if isinstance(v, MDPVehicle) else 2]  # kind: 1 controlled CAV, 2 HDV (IDMVehicle / IDMVehicleHist)
     return f, i
 
 
@@ -73,7 +75,7 @@ def _road_step_logged(self, dt):
 Road.step = _road_step_logged
 
 
-def make_env(env_id, shield, n_cav, headway_time, eta):
+def make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=0):
     """Mirror of how run_mappo.py:137-171 configures an env (values from the cited .ini files)."""
     CBFType.GAMMA_B = eta
     CBFType.TAU = headway_time
@@ -90,11 +92,11 @@ def make_env(env_id, shield, n_cav, headway_time, eta):
     env.config["action_masking"] = False
     env.config["safety_guarantee"] = shield
     env.config["lateral_control"] = "steer"
-    env.config["mixed_traffic"] = False
-    env.config["traffic_type"] = "cav"
+    env.config["mixed_traffic"] = n_hdv > 0
+    env.config["traffic_type"] = "mixed" if n_hdv > 0 else "cav"
     env.config["agent_reward"] = "default"
     # BASELINE configs fix the vehicle count (N CAVs, 0 HDVs); the reference draws it at random.
-    env._num_vehicles = lambda num_CAV=0: (n_cav, 0)
+    env._num_vehicles = lambda num_CAV=0: (n_cav, n_hdv)
     return env
 
 
@@ -114,14 +116,14 @@ def _place_vehicles(env, placement):
 
 
 def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta, p=None,
-                max_steps=100, scripted=None, placement=None):
+                max_steps=100, scripted=None, placement=None, n_hdv=0):
     global _SUBSTEP_LOG
-    env = make_env(env_id, shield, n_cav, headway_time, eta)
+    env = make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=n_hdv)
     obs0, mask0 = env.reset(is_training=False, testing_seeds=seed)
     if placement is not None:
         obs0 = _place_vehicles(env, placement)
     n = len(env.controlled_vehicles)
-    assert n == n_cav and len(env.road.vehicles) == n_cav
+    assert n == n_cav and len(env.road.vehicles) == n_cav + n_hdv
     init_f, init_i = zip(*[_veh_snapshot(v) for v in env.road.vehicles])
     rng = np.random.RandomState(tape_seed)
     p = p or [0.1, 0.6, 0.1, 0.1, 0.1]
@@ -169,7 +171,7 @@ def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta,
         qp_G[k, :g.shape[0]] = g
         qp_h[k, :h.shape[0]] = h
         qp_x[k] = x
-    meta = dict(env_id=env_id, shield=shield, n=n_cav, seed=seed, tape_seed=tape_seed,
+    meta = dict(env_id=env_id, shield=shield, n=n_cav, n_hdv=n_hdv, seed=seed, tape_seed=tape_seed,
                 headway_time=headway_time, eta=eta, n_merge=int(env.n_merge),
                 n_s=int(env.n_s), crashed=bool(env.is_crashed()), steps=t,
                 qp_solver="exact-KKT closed form (cvxopt 1.2.7 unavailable)")
@@ -368,6 +370,15 @@ def main():
         for tag, shield in (("none", "none"), ("hss", "cbf-avs_cint"), ("mass", "cbf-cav")):
             metas.append(run_episode("sc_%s_%s" % (sname, tag), v1, shield, len(placement), 0, 0, 0.5, 0.03125,
                                      scripted=script, placement=placement))
+    # (4) mixed traffic: CAVs + IDM/MOBIL HDVs (behavior.py:74-266; configs *-mixed*.ini)
+    for seed, (nc, nh) in ((0, (3, 3)), (25, (2, 2)), (50, (4, 4))):
+        metas.append(run_episode("mx_v0_none_%dc%dh_s%d" % (nc, nh, seed), v0, "none", nc, seed, 31 + seed, 1.2, 0.0, n_hdv=nh))
+    for seed, (nc, nh) in ((0, (3, 3)), (25, (4, 3)), (50, (2, 2)), (75, (6, 5))):
+        metas.append(run_episode("mx_v1_none_%dc%dh_s%d" % (nc, nh, seed), v1, "none", nc, seed, 41 + seed, 0.5, 0.0, n_hdv=nh))
+        metas.append(run_episode("mx_v1_hss_%dc%dh_s%d" % (nc, nh, seed), v1, "cbf-avs_cint", nc, seed, 41 + seed, 0.5, 0.03125, n_hdv=nh))
+        metas.append(run_episode("mx_v1_mass_%dc%dh_s%d" % (nc, nh, seed), v1, "cbf-cav", nc, seed, 41 + seed, 0.5, 0.03125, n_hdv=nh))
+    lc = [0.3, 0.2, 0.3, 0.1, 0.1]
+    metas.append(run_episode("mx_v1_mass_4c4h_lc_s100", v1, "cbf-cav", 4, 100, 7, 0.5, 0.03125, p=lc, n_hdv=4))
     with open(os.path.join(OUT, "index.json"), "w") as fh:
         json.dump(metas, fh, indent=1)
 
