@@ -121,8 +121,15 @@ class MergeEnvCompat(object):
                 cfg["mixed_traffic"] = True
             elif tt == "cav":
                 cfg["mixed_traffic"] = False
-            elif tt in ("av", "hdv"):
-                raise NotImplementedError("traffic_type=%r needs HDVs (IDM/MOBIL), not on the hot path yet" % tt)
+            elif tt == "av":  # merge_env_v1.py:485-489: one CAV, everything else HDV
+                num_CAV, num_HDV = self._draw_counts(num_CAV)
+                return 1, num_CAV + num_HDV - 1
+            elif tt == "hdv":
+                raise NotImplementedError("traffic_type='hdv' (no controlled vehicle, MergeEnvLCHDV) is out of scope")
+        return self._draw_counts(num_CAV)
+
+    def _draw_counts(self, num_CAV=0):
+        cfg = self.config
         num_HDV = 0
         lo_hi = {1: ((1, 4), (1, 4)), 2: ((2, 5), (2, 5)), 3: ((4, 7), (3, 6))}.get(cfg["traffic_density"])
         if lo_hi:
@@ -134,10 +141,9 @@ class MergeEnvCompat(object):
         return int(num_CAV), int(num_HDV)
 
     def _make_vehicles(self, num_CAV, num_HDV):
-        """merge_env_v1.py:265-364, CAV part; same global-RNG draws in the same order."""
-        if num_HDV:
-            raise NotImplementedError("mixed traffic (HDVs) is not on the hot path yet (SURVEY 8f-2)")
-        if num_CAV > MAX_VEHICLES:
+        """merge_env_v1.py:265-364; same global-RNG draws in the same order.  Returns x, y, speed of
+        all vehicles in creation order (CAVs main, CAVs ramp, HDVs main, HDVs ramp) and n_merge."""
+        if num_CAV + num_HDV > MAX_VEHICLES:
             raise ValueError("at most %d vehicles (6 + 6 spawn slots)" % MAX_VEHICLES)
         spawn_points_s = [10, 60, 110, 160, 210, 260]
         spawn_points_m = [5, 55, 105, 155, 205, 255]
@@ -149,9 +155,10 @@ class MergeEnvCompat(object):
             spawn_points_s.remove(a)
         for b in spawn_point_m_c:
             spawn_points_m.remove(b)
-        # the HDV draws still happen in the reference with sizes 0 (num_HDV // 2 == 0)
-        np.random.choice(spawn_points_s, 0, replace=False)
-        np.random.choice(spawn_points_m, 0, replace=False)
+        num_s_h = num_HDV // 2 if num_HDV != 1 else np.random.choice(2)
+        num_m_h = num_HDV - num_s_h
+        spawn_point_s_h = list(np.random.choice(spawn_points_s, num_s_h, replace=False))
+        spawn_point_m_h = list(np.random.choice(spawn_points_m, num_m_h, replace=False))
         initial_speed = list(np.random.rand(num_CAV + num_HDV) * 2 + 25)
         loc_noise = list(np.random.rand(num_CAV + num_HDV) * 8 - 4)
         x, y, v = [], [], []
@@ -159,6 +166,10 @@ class MergeEnvCompat(object):
             x.append(spawn_point_s_c.pop(0) + loc_noise.pop(0)); y.append(0.0); v.append(initial_speed.pop(0))
         for _ in range(num_m_c):
             x.append(spawn_point_m_c.pop(0) + loc_noise.pop(0)); y.append(6.5 + 4); v.append(initial_speed.pop(0))
+        for _ in range(num_s_h):
+            x.append(spawn_point_s_h.pop(0) + loc_noise.pop(0)); y.append(0.0); v.append(initial_speed.pop(0))
+        for _ in range(num_m_h):
+            x.append(spawn_point_m_h.pop(0) + loc_noise.pop(0)); y.append(6.5 + 4); v.append(initial_speed.pop(0))
         return np.array(x, dtype=np.float64), np.array(y), np.array(v, dtype=np.float64), int(num_m_c)
 
     def _backend(self):
@@ -185,14 +196,16 @@ class MergeEnvCompat(object):
         self.n_merge = n_merge
         self.T = int(self.config["duration"] * self.config["policy_frequency"])
         b = self._backend()
-        b.configure(self.config, cbf_eta=CBFType.GAMMA_B, cbf_tau=CBFType.TAU)
-        self._n = n = len(x)
-        pad = lambda a, fill: np.concatenate([a, np.full(MAX_VEHICLES - n, fill)])  # noqa: E731
+        b.configure(self.config, cbf_eta=CBFType.GAMMA_B, cbf_tau=CBFType.TAU, n_hdv=n_hdv)
+        n_all = len(x)
+        self._n = n = n_cav
+        pad = lambda a, fill: np.concatenate([a, np.full(MAX_VEHICLES - n_all, fill)])  # noqa: E731
+        kind = pad(np.array([1] * n_cav + [2] * n_hdv), 0)
         obs, avail = b.set_kinematics(pad(x, np.nan)[None], pad(y, 0.0)[None], np.zeros((1, MAX_VEHICLES)),
-                                      pad(v, 0.0)[None], n_merge=np.array([n_merge]))
+                                      pad(v, 0.0)[None], n_merge=np.array([n_merge]), kind=kind[None])
         self.road = _Road()
-        self.controlled_vehicles = [_VehicleView(self, i) for i in range(n)]
-        self.road.vehicles = list(self.controlled_vehicles)
+        self.controlled_vehicles = [_VehicleView(self, i) for i in range(n_cav)]
+        self.road.vehicles = self.controlled_vehicles + [_VehicleView(self, i) for i in range(n_cav, n_all)]
         return (obs[0, :n].cpu().numpy().astype(np.float64).reshape(n, -1),
                 avail[0, :n].cpu().numpy().astype(np.int64))
 

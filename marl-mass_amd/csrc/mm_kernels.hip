@@ -28,7 +28,7 @@
 using namespace mm;
 
 struct DevCfg {
-  int env_kind, shield, nsub, T, action_masking, auto_reset, obs_f64, N, E, debug_flags;
+  int env_kind, shield, nsub, T, action_masking, auto_reset, obs_f64, N, E, debug_flags, n_hdv;
   double dt, collision_reward, high_speed_reward, headway_cost, headway_time, merging_lane_cost;
   double rs_lo, rs_hi, eta, tau;
   double inv_dt, rs_span, rs_ispan;  // host-computed reciprocals for div_c (correctly rounded 1/d)
@@ -47,6 +47,7 @@ struct Veh {
   double act_steer, act_acc, safe_steer, safe_acc, gvx;
   double h1x, h1vx, h2x, h2vx;  // x / vx of state_hist[-1], [-2]
   int lane, tlane, sidx, crashed, hl, flags, hist_len;
+  int kind;  // 0 absent, 1 controlled CAV, 2 HDV (for an HDV `gvx` holds the MOBIL timer, see mm_abi.h)
   bool present;
 };
 
@@ -123,7 +124,8 @@ MM_DEV void load_veh(const DevState &st, long long i, bool valid, Veh &v) {
   v.hl = MM_HL_NONE;
   if (!valid) return;
   const long long A = st.A;
-  v.present = st.B[MM_B_KIND * A + i] != 0;
+  v.kind = st.B[MM_B_KIND * A + i];
+  v.present = v.kind != 0;
   if (!v.present) return;
   v.x = st.F[MM_F_X * A + i]; v.y = st.F[MM_F_Y * A + i]; v.h = st.F[MM_F_HEADING * A + i];
   v.v = st.F[MM_F_SPEED * A + i]; v.tspeed = st.F[MM_F_TARGET_SPEED * A + i];
@@ -135,12 +137,14 @@ MM_DEV void load_veh(const DevState &st, long long i, bool valid, Veh &v) {
   v.sidx = st.B[MM_B_SPEED_INDEX * A + i]; v.crashed = st.B[MM_B_CRASHED * A + i];
   v.hl = st.B[MM_B_HL_ACTION * A + i]; v.flags = st.B[MM_B_FLAGS * A + i];
   v.hist_len = st.B[MM_B_HIST_LEN * A + i];
+  if (v.kind == 2) { v.act_steer = v.safe_steer; v.act_acc = v.safe_acc; }  // last IDM action persists
 }
 MM_DEV void store_veh(const DevState &st, long long i, const Veh &v) {
   const long long A = st.A;
   st.F[MM_F_X * A + i] = v.x; st.F[MM_F_Y * A + i] = v.y; st.F[MM_F_HEADING * A + i] = v.h;
   st.F[MM_F_SPEED * A + i] = v.v; st.F[MM_F_TARGET_SPEED * A + i] = v.tspeed;
-  st.F[MM_F_SAFE_STEER * A + i] = v.safe_steer; st.F[MM_F_SAFE_ACC * A + i] = v.safe_acc;
+  st.F[MM_F_SAFE_STEER * A + i] = v.kind == 2 ? v.act_steer : v.safe_steer;
+  st.F[MM_F_SAFE_ACC * A + i] = v.kind == 2 ? v.act_acc : v.safe_acc;
   st.F[MM_F_G_VX * A + i] = v.gvx;
   st.F[MM_F_H1_X * A + i] = v.h1x; st.F[MM_F_H1_VX * A + i] = v.h1vx;
   st.F[MM_F_H2_X * A + i] = v.h2x; st.F[MM_F_H2_VX * A + i] = v.h2vx;
@@ -188,12 +192,11 @@ MM_DEV void hl_act(Veh &v, int action) {
 }
 
 // kinematics.py:143-152 clip_actions (+ safe_controller.py:100-104)
-template <int KIND>
-MM_DEV void clip_actions(Veh &v) {
+MM_DEV void clip_actions(Veh &v, bool lc_vehicle) {
   if (v.crashed) { v.act_steer = 0; v.act_acc = -1.0 * v.v; }
   if (v.v > kMaxSpeed) v.act_acc = fmin(v.act_acc, 1.0 * (kMaxSpeed - v.v));
   else if (v.v < -kMaxSpeed) v.act_acc = fmax(v.act_acc, 1.0 * (kMaxSpeed - v.v));
-  if (KIND == MM_ENV_V1) v.act_acc = clipd(v.act_acc, kLcMinAcc, kLcMaxAcc);
+  if (lc_vehicle) v.act_acc = clipd(v.act_acc, kLcMinAcc, kLcMaxAcc);  // MDPLCVehicle only
 }
 
 // controller.py:257-267 get_corner("L"/"R") + lane.on_lane of those corners on `lane`
@@ -254,23 +257,35 @@ struct QpTrace {
 MM_DEV void init_vehicle(Veh &v) {  // kinematics.py:36-53, controller.py:35-50,277-291, safe_controller.py:27-61
   v.lane = closest_lane(v.x, v.y, v.h);
   v.tlane = v.lane;
-  v.sidx = speed_to_index(v.v);
-  v.tspeed = index_to_speed(v.sidx);
   v.act_steer = v.act_acc = 0;
   v.safe_steer = v.safe_acc = 0;
-  v.gvx = __builtin_nan("");
+  if (v.kind == 2) {  // IDMVehicle.__init__ behavior.py:42-53: target_speed = speed, timer = (sum(pos) * pi) % 1
+    v.sidx = 0;
+    v.tspeed = v.v;
+    v.gvx = py_mod((v.x + v.y) * kPi, 1.0);
+  } else {
+    v.sidx = speed_to_index(v.v);
+    v.tspeed = index_to_speed(v.sidx);
+    v.gvx = __builtin_nan("");
+  }
   v.h1x = v.h1vx = v.h2x = v.h2vx = 0;
   v.crashed = 0; v.hl = MM_HL_NONE; v.flags = 0; v.hist_len = 0;
 }
-MM_DEV int spawn_vehicle(Veh &v, int a, int N, uint64_t seed, uint32_t episode) {
+MM_DEV int spawn_vehicle(Veh &v, int a, int n_cav, int n_hdv, uint64_t seed, uint32_t episode) {
   uint32_t r[12], blk[4];
   rng_block(seed, episode, 0, &r[0]);
   rng_block(seed, episode, 1, &r[4]);
   rng_block(seed, episode, 2, &r[8]);
-  int n_s = (N != 1) ? N / 2 : (int)(r[0] & 1u);
-  int n_m = N - n_s;
-  bool main_road = a < n_s;
-  int k = main_road ? a : a - n_s;
+  const int n_s = (n_cav != 1) ? n_cav / 2 : (int)(r[0] & 1u);
+  const int n_m = n_cav - n_s;
+  const int n_sh = (n_hdv != 1) ? n_hdv / 2 : (int)((r[0] >> 1) & 1u);
+  // creation order: CAV main, CAV ramp, HDV main, HDV ramp; HDV slots continue the CAV shuffle
+  bool main_road;
+  int k;  // index into the road's shuffled slot list
+  if (a < n_s) { main_road = true; k = a; }
+  else if (a < n_cav) { main_road = false; k = a - n_s; }
+  else if (a < n_cav + n_sh) { main_road = true; k = n_s + (a - n_cav); }
+  else { main_road = false; k = n_m + (a - n_cav - n_sh); }
   int slots[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) slots[i] = (main_road ? 10 : 5) + 50 * i;
@@ -296,6 +311,7 @@ MM_DEV int spawn_vehicle(Veh &v, int a, int N, uint64_t seed, uint32_t episode) 
   v.y = main_road ? 0.0 : 10.5;
   v.h = 0;
   v.v = speed;
+  v.kind = a < n_cav ? 1 : 2;
   v.present = true;
   init_vehicle(v);
   return n_m;
@@ -308,6 +324,7 @@ template <int G, int KIND>
 MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, bool valid, void *obs,
                     uint8_t *avail) {
   constexpr int F = (KIND == MM_ENV_V1) ? 6 : 5;
+  const bool ctrl = v.present && v.kind != 2;  // only controlled vehicles observe / have an action mask
   double sps, cps;
   mmm_sincos(v.h, &sps, &cps);
   const double vx = v.v * cps, vy = v.v * sps;  // Vehicle.velocity kinematics.py:215-217
@@ -355,12 +372,12 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
   auto lmap = [&](double val, int f) { return -1 + div_c((val - lo[f]) * (1 - (-1)), span[f], ispan[f]); };
   const double ego[5] = {v.x, v.y, vx, vy, v.h};
   auto emit = [&](auto put) {
-    put(0, v.present ? 1.0 : 0.0);
+    put(0, ctrl ? 1.0 : 0.0);
 #pragma unroll
-    for (int f = 0; f < F - 1; f++) put(1 + f, v.present ? lmap(ego[f], f) : 0.0);
+    for (int f = 0; f < F - 1; f++) put(1 + f, ctrl ? lmap(ego[f], f) : 0.0);
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const bool hq = v.present && have[q];
+      const bool hq = ctrl && have[q];
       put((q + 1) * F, hq ? 1.0 : 0.0);
 #pragma unroll
       for (int f = 0; f < F - 1; f++)
@@ -398,7 +415,7 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
   unsigned bits = 0x1F;
   if (c.action_masking) {
     unsigned mine = 0;
-    if (v.present) {
+    if (ctrl) {
       mine = 1u << 1;
       if (v.lane == MM_LANE_BC1 && lane_reachable(MM_LANE_BC0, v.x, v.y)) mine |= 1u << 0;
       if (v.lane == MM_LANE_BC0 && lane_reachable(MM_LANE_BC1, v.x, v.y)) mine |= 1u << 2;
@@ -412,8 +429,51 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
   }
   if (valid && avail) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) avail[i * 5 + k] = v.present ? (uint8_t)((bits >> k) & 1u) : (uint8_t)0;
+    for (int k = 0; k < 5; k++) avail[i * 5 + k] = ctrl ? (uint8_t)((bits >> k) & 1u) : (uint8_t)0;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// HDVs: IDM + MOBIL (vehicle/behavior.py:74-266), mixed traffic only (MIXED kernels)
+// ------------------------------------------------------------------------------------------------
+struct Body {  // what IDM reads of a vehicle / object
+  bool present, is_object;
+  double x, y, h, v, tspeed;
+  int lane;
+};
+MM_DEV double desired_gap(const Body &ego, const Body &front) {  // behavior.py:141-156 (projected)
+  const double ab = 15.0;  // -COMFORT_ACC_MAX * COMFORT_ACC_MIN
+  double es, ec, fs, fc;
+  mmm_sincos(ego.h, &es, &ec);
+  mmm_sincos(front.h, &fs, &fc);
+  const double evx = ego.v * ec, evy = ego.v * es, fvx = front.v * fc, fvy = front.v * fs;
+  const double dv = (evx - fvx) * ec + (evy - fvy) * es;
+  return 10.0 + ego.v * 1.5 + ego.v * dv / (2 * sqrt(ab));
+}
+MM_DEV double idm_acceleration(const Body &ego, const Body &front) {  // behavior.py:111-139
+  if (!ego.present || ego.is_object) return 0;
+  const double target = not_zero(ego.tspeed);
+  double q = fmax(ego.v, 0) / target;
+  double q2 = q * q;
+  double acc = 3.0 * (1 - q2 * q2);  // np.power(., 4) as (x^2)^2 (oracle math mode 1)
+  if (front.present) {
+    const double sx = lane_sx(ego.lane);
+    const double d = (front.x - sx) - (ego.x - sx);  // ego.lane_distance_to(front)
+    const double g = desired_gap(ego, front) / not_zero(d);
+    acc -= 3.0 * (g * g);
+  }
+  return acc;
+}
+// one candidate of road.neighbour_vehicles(lane) (road.py:352-381): keeps the running front / rear.
+// idx = creation index (obstacle: 99, it is scanned last); ties follow the reference's loop order.
+MM_DEV void neighbour_update(int lane, double s_me, const Body &b, int idx, Body &front, double &s_front, int &i_front,
+                             Body &rear, double &s_rear, int &i_rear) {
+  if (!b.present) return;
+  double s_v = b.x - lane_sx(lane), lat = b.y - lane_sy(lane);
+  if (lane == MM_LANE_KB0) lat = lat - kSineAmp * mmm_sin(kSinePuls * s_v + kSinePhase);
+  if (!(fabs(lat) <= kLaneWidth / 2 + 1 && (-kVehLength <= s_v && s_v < lane_len(lane) + kVehLength))) return;
+  if (s_me <= s_v && (i_front < 0 || s_v < s_front || (s_v == s_front && idx > i_front))) { s_front = s_v; i_front = idx; front = b; }
+  if (s_v < s_me && (i_rear < 0 || s_v > s_rear || (s_v == s_rear && idx < i_rear))) { s_rear = s_v; i_rear = idx; rear = b; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -553,14 +613,14 @@ MM_DEV ShieldOut shield_eval(const DevCfg &c, const Veh &v, double cpsi, bool of
 
 // Relation of vehicle `o` (as the ego currently sees it) to the ego: the branch conditions of the
 // loop in multi_agent_state (decentral_layer.py:104-211).  cls: 0 none, 1 leader, 2 front-adjacent,
-// 3 rear-adjacent.  cflag: constrain_adj candidate = the relevant front corner of `o` left its lane.
+// 3 rear-adjacent, 4 on-ramp HDV twin.  cflag: constrain_adj candidate = the relevant front corner of `o` left its lane.
 struct Rel {
   double key;  // |ego.lane_distance_to(o)| or inf when o is not within the perception distance
   int cls;
   bool cflag;
 };
 MM_DEV Rel relate(double ex, double ey, int elane, int enl, bool other, double ox, double oy, double oh, int olane,
-                  int onl, bool ooffL, bool ooffR) {
+                  int onl, bool ooffL, bool ooffR, bool o_hdv = false) {
   Rel r;
   const double dx = ox - ex, dy = oy - ey;
   const bool close = other && sqrt(dx * dx + dy * dy) < kPerception;  // road.py:259-262
@@ -574,6 +634,8 @@ MM_DEV Rel relate(double ex, double ey, int elane, int enl, bool other, double o
   r.cls = 0;
   if (close) {
     if (adj) r.cls = ld < 0 ? 3 : 2;
+    // :162-184 HDV on the merging lane next to an ego on ab0: "digital twin" slot (class 4)
+    else if (o_hdv && elane == MM_LANE_AB0 && olane == MM_LANE_KB0 && ld >= 0) r.cls = 4;
     else if ((same || appr) && ld > 0) r.cls = 1;
   }
   r.cflag = (v_a == -1 || a_v == 1) ? ooffL : ooffR;  // :146-152 which front corner of `o`
@@ -586,7 +648,7 @@ MM_DEV Rel relate(double ex, double ey, int elane, int enl, bool other, double o
 #ifndef MM_MIN_WAVES
 #define MM_MIN_WAVES 2  // 2 waves/SIMD: measured 0.62 ms vs 0.98 (1) / 0.92 (3, spills) at 65536x8 MASS
 #endif
-template <int G, int KIND, int SHIELD>
+template <int G, int KIND, int SHIELD, bool MIXED>
 __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
                                                    MMStepOut out, double *metrics) {
   constexpr bool LC = (KIND == MM_ENV_V1);
@@ -608,13 +670,17 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     steps = st.I[MM_E_STEPS * st.E + e]; time = st.I[MM_E_TIME * st.E + e];
     n_merge = st.I[MM_E_N_MERGE * st.E + e]; episode = st.I[MM_E_EPISODE * st.E + e];
   }
-  const int action = (valid && v.present) ? actions[i] : 1;
+  if (!MIXED && v.kind == 2) v.kind = 1;  // CAV-only kernels: the host guarantees there are no HDVs
+  const bool hdv = MIXED && v.kind == 2;
+  const bool ctrl = v.present && !hdv;  // controlled vehicle (MDPVehicle / MDPLCVehicle)
+  const int action = (valid && ctrl) ? actions[i] : 1;
   const unsigned present_bits = group_ballot<G>(v.present, gb);
-  const int n_veh = __popc(present_bits);
+  const unsigned ctrl_bits = group_ballot<G>(ctrl, gb);
+  const int n_veh = __popc(present_bits), n_ctrl = __popc(ctrl_bits);
   steps += 1;  // abstract.py:457
 
   // derived per-vehicle registers the shield keeps current across sub-steps
-  double cpsi = (SHIELDED && v.present) ? mmm_cos(v.h) : 1.0;
+  double cpsi = ((SHIELDED || MIXED) && v.present) ? mmm_cos(v.h) : 1.0;
   bool offL = false, offR = false;
   int nl_self = 0;
   if (SHIELDED && v.present) {
@@ -622,20 +688,116 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     nl_self = next_lane(v.lane, v.x, v.y);
   }
 
-  bool env_active = n_veh > 0;
+  bool env_active = n_ctrl > 0;
   for (int k = 0; k < c.nsub; k++) {
     const bool live = env_active && v.present;
     QpTrace qt = {0, __builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan(""),
                   __builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
-    if (live) {
-      if (time % c.nsub == 0) hl_act<KIND>(v, action);  // action_type.act abstract.py:516-519
-      controlled_act(v, -1);                             // road.act road.py:269-278
-      clip_actions<KIND>(v);
+    // Road.act / Road.step order: sorted by x descending, stable (road.py:277,286) -> rank
+    int rank = 0;
+    if (SHIELDED || MIXED) {
+      for_partners<G>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        double px = dppx_d<m>(v.x);
+        bool pp = dppx_i<m>((int)live) != 0;
+        rank += (pp && (px > v.x || (px == v.x && (a ^ m) < a))) ? 1 : 0;
+      });
     }
+    if (live && !hdv) {
+      if (time % c.nsub == 0) hl_act<KIND>(v, action);  // action_type.act abstract.py:516-519
+    }
+    const int tl_pre = v.tlane;  // what an HDV acting before this vehicle still sees
+    if (live && !hdv) controlled_act(v, -1);  // road.act road.py:269-278
+    if constexpr (MIXED) {
+      // ---------------- IDMVehicle.act for the HDVs (behavior.py:74-100) -------------------------
+      // Positions do not move during Road.act, so each HDV scans its neighbours in parallel.  The one
+      // thing acted-upon state an HDV reads is other vehicles' target_lane_index (ongoing-LC abort
+      // test, :193-206): it sees the post-act value of vehicles ahead of it in the sweep, the pre-act
+      // value of the others; HDV decisions ahead feed HDVs behind -> small fixed point on tl_post.
+      if (__any(hdv && live)) {
+        const bool acting = hdv && live && !v.crashed;
+        Body self = {true, false, v.x, v.y, v.h, v.v, v.tspeed, v.lane};
+        const double s_me = v.x - lane_sx(v.lane);
+        Body front0 = {}, rear0 = {};
+        double sf0 = 0, sr0 = 0;
+        int if0 = -1, ir0 = -1;
+        if (acting && lane_after_end(v.tlane, v.x)) v.tlane = next_lane(v.tlane, v.x, v.y);  // follow_road
+        const int my_tl = v.tlane;
+        const bool lc_branch = v.lane != my_tl;  // a lane change is under way (:191)
+        const bool same_road = lane_road(v.lane) == lane_road(my_tl);
+        const bool timer_due = !lc_branch && (1.0 < v.gvx);  // utils.do_every(LANE_CHANGE_DELAY, timer)
+        const int side = v.lane == MM_LANE_BC0 ? MM_LANE_BC1 : (v.lane == MM_LANE_BC1 ? MM_LANE_BC0 : -1);
+        const bool try_mobil = acting && timer_due && side >= 0 && lane_reachable(side < 0 ? 0 : side, v.x, v.y);
+        const int sl = side < 0 ? 0 : side;
+        const double s_side = v.x - lane_sx(sl);
+        Body front1 = {}, rear1 = {};
+        double sf1 = 0, sr1 = 0;
+        int if1 = -1, ir1 = -1;
+        unsigned abort_mask = 0;  // partners that would make me abort IF they target my target lane
+        unsigned tl_all = 0;      // 3 bits per partner: its pre / post target lane is exchanged below
+        (void)tl_all;
+        for_partners<G>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          const int p = a ^ m;
+          Body b;
+          b.present = dppx_i<m>((int)live) != 0;
+          b.is_object = false;
+          b.x = dppx_d<m>(v.x); b.y = dppx_d<m>(v.y); b.h = dppx_d<m>(v.h); b.v = dppx_d<m>(v.v);
+          b.tspeed = dppx_d<m>(v.tspeed);
+          b.lane = dppx_i<m>(v.lane);
+          if (acting) {
+            neighbour_update(v.lane, s_me, b, p, front0, sf0, if0, rear0, sr0, ir0);
+            if (try_mobil) neighbour_update(sl, s_side, b, p, front1, sf1, if1, rear1, sr1, ir1);
+            if (lc_branch && same_road && b.present && b.lane != my_tl) {
+              const double sx = lane_sx(v.lane);
+              const double d = (b.x - sx) - (v.x - sx);
+              if (0 < d && d < desired_gap(self, b)) abort_mask |= 1u << p;
+            }
+          }
+        });
+        if (acting) {  // road.objects come after the vehicles (road.py:369)
+          Body ob = {true, true, kObstX, kObstY, 0.0, 0.0, 0.0, 0};
+          neighbour_update(v.lane, s_me, ob, 99, front0, sf0, if0, rear0, sr0, ir0);
+          if (try_mobil) neighbour_update(sl, s_side, ob, 99, front1, sf1, if1, rear1, sr1, ir1);
+        }
+        bool mobil_go = false;
+        if (try_mobil) {  // mobil() behavior.py:225-266 (no route, POLITENESS = 0)
+          const double nf_pred = idm_acceleration(rear1, self);
+          if (!(nf_pred < -9.0)) {
+            const double jerk = idm_acceleration(self, front1) - idm_acceleration(self, front0) + 0.0;
+            mobil_go = !(jerk < 0.1);
+          }
+        }
+        if (acting && timer_due) v.gvx = 0;  // self.timer = 0 (:212)
+        // fixed point on the post-act target lanes
+        int tl_post = acting ? (lc_branch ? my_tl : (mobil_go ? side : my_tl)) : v.tlane;
+        for (int round = 0; round <= st.N; round++) {
+          bool hit = false;
+          for_partners<G>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const int p = a ^ m;
+            const int pk = dppx_i<m>(rank | tl_pre << 4 | tl_post << 8);
+            const int p_tl = ((pk & 15) < rank) ? ((pk >> 8) & 7) : ((pk >> 4) & 7);  // acted before me?
+            hit = hit || (((abort_mask >> p) & 1u) && p_tl == my_tl);
+          });
+          const int nxt = (acting && lc_branch) ? ((same_road && hit) ? v.lane : my_tl) : tl_post;
+          const bool changed = nxt != tl_post;
+          tl_post = nxt;
+          if (!__any(changed)) break;
+        }
+        if (acting) {
+          v.tlane = tl_post;
+          v.act_steer = clipd(steering_control(v.x, v.y, v.h, v.v, v.tlane), -kPi / 3, kPi / 3);
+          v.act_acc = clipd(idm_acceleration(self, front0), -6.0, 6.0);
+        }
+      }
+      if (hdv && live) v.gvx += dt;  // IDMVehicle.step: self.timer += dt (behavior.py:102-109)
+    }
+    if (live) clip_actions(v, LC && !hdv);
     // predicted post-state for the nominal steering (the only one when nothing vetoes)
     Cand cA, cB;
     memset(&cA, 0, sizeof cA);
-    const bool shield_on = SHIELDED && live && v.hist_len >= 2;  // gate safe_controller.py:232-239
+    const bool shield_on = SHIELDED && live && !hdv && v.hist_len >= 2;  // gate safe_controller.py:232-239
     if (live) cA = predict<KIND, SHIELDED>(v, v.act_steer, dt);
     cB = cA;
     double steerB = v.act_steer;
@@ -656,14 +818,6 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     int new_flags = v.flags;
 
     if (SHIELDED && __any(shield_on)) {
-      // Road.step order: sorted by x descending, stable (road.py:286) -> rank; lower = steps earlier
-      int rank = 0;
-      for_partners<G>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        double px = dppx_d<m>(v.x);
-        bool pp = dppx_i<m>((int)live) != 0;
-        rank += (pp && (px > v.x || (px == v.x && (a ^ m) < a))) ? 1 : 0;
-      });
       bool serial = (c.debug_flags & 1) != 0;
       ShieldOut so;
       memset(&so, 0, sizeof so);
@@ -697,17 +851,23 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
             const int spk = i_first ? (mine.lane | mine.nl << 3 | (int)mine.offL << 6 | (int)mine.offR << 7)
                                     : (v.lane | nl_self << 3 | (int)offL << 6 | (int)offR << 7);
             const double shx = i_first ? v.h1x : v.h2x, shvx = i_first ? v.h1vx : v.h2vx;  // my state_hist[-2] as seen then
-            const double sg = i_first ? mine.gvx : v.gvx;
-            const double sacc = v.safe_acc;   // my previous decision (read only if I have not stepped)
+            // an HDV has no safe_action / fg_params: followers assume (0, -12.5) and g.vx = 1 (:129-135,:205-211)
+            const double sg = hdv ? 1.0 : (i_first ? mine.gvx : v.gvx);
+            const double sacc = hdv ? kCbfAccLo : v.safe_acc;  // my previous decision (read only if I have not stepped)
             const double svx = v.v * cpsi;    // my current vx (rear-adjacent slot reads to_dict())
             const double ox = dppx_d<m>(sx_), oy = dppx_d<m>(sy_), oh = dppx_d<m>(sh_);
-            const int opk = dppx_i<m>(spk | (int)live << 8);
+            const int opk = dppx_i<m>(spk | (int)live << 8 | (int)hdv << 9);
             const double ohx = dppx_d<m>(shx), ohvx = dppx_d<m>(shvx), og = dppx_d<m>(sg);
             const double oacc = dppx_d<m>(sacc), ovx = dppx_d<m>(svx);
-            const bool o_first = !i_first && p_rank < 99;  // partner steps before me (ranks are distinct)
+            const bool o_hdv = MIXED && ((opk >> 9) & 1) != 0;
+            // partner steps before me (ranks are distinct); an HDV's "decision" is the static worst case
+            const bool o_first = !i_first && p_rank < 99 && !o_hdv;
             const Rel r = relate(v.x, v.y, v.lane, nl_self, ((opk >> 8) & 1) != 0, ox, oy, oh, opk & 7, (opk >> 3) & 7,
-                                 ((opk >> 6) & 1) != 0, ((opk >> 7) & 1) != 0);
+                                 ((opk >> 6) & 1) != 0, ((opk >> 7) & 1) != 0, o_hdv);
             keys[m] = r.key;
+            // the on-ramp HDV "digital twin" edits the HDV's history record in place (:175-180), which
+            // later egos of the sub-step read: an order dependence only the literal sweep reproduces
+            if (MIXED && r.cls == 4) irregular = irregular || shield_on;
             // running "first in sorted order" per class: smaller key, ties by creation index
             if (r.cls == 1 && (r.key < k_ol || (r.key == k_ol && p < j_ol))) {
               k_ol = r.key; j_ol = p; nb.ol_x = ohx; nb.ol_vx = ohvx; nb.ol_g = og; nb.ol_acc = oacc; ol_dyn = o_first;
@@ -717,7 +877,7 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
               nb.constrain_adj = r.cflag;
             }
             if (r.cls == 3 && (r.key < k_oar || (r.key == k_oar && p < j_oar))) {
-              k_oar = r.key; j_oar = p; nb.oar_x = ox; nb.oar_vx = ovx; oar_stepped = o_first;
+              k_oar = r.key; j_oar = p; nb.oar_x = ox; nb.oar_vx = ovx; oar_stepped = !i_first && p_rank < 99;
             }
           });
           // count = 5 of close_vehicles_to: a slot exists only if its vehicle is among the 5 nearest
@@ -778,18 +938,31 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
         make_B();
         use_B = false; veto = false; new_acc = v.act_acc; new_flags = v.flags;
         // working copy of what the others see of me; committed stage by stage
-        double wx = v.x, wy = v.y, wh = v.h, wg = v.gvx, wacc = v.safe_acc, wvx = v.v * cpsi;
+        double wx = v.x, wy = v.y, wh = v.h, wg = hdv ? 1.0 : v.gvx, wacc = hdv ? kCbfAccLo : v.safe_acc, wvx = v.v * cpsi;
         double whx = v.h2x, whvx = v.h2vx;
         int wlane = v.lane, wnl = nl_self;
         bool woffL = offL, woffR = offR;
+        if (MIXED && hdv && live) {
+          // HDVs take no part in the shield: publish their stepped view when the sweep passes them
+          // (done below by rank), here only note that their record [-2] after stepping is the old [-1]
+        }
+        bool w_stepped = false;  // my published view is already the post-step one
+        double twin_shift = 0;   // in-place edits egos made to my history record this sub-step
         for (int r = 0; r < st.N; r++) {
+          if (MIXED && live && hdv && rank == r && !w_stepped) {
+            // an HDV at its turn just steps (no shield): later egos see its post-step pose, and its
+            // state_hist[-2] is then the record it held as [-1] before
+            wx = cA.x; wy = cA.y; wh = cA.h; wlane = cA.lane; wnl = cA.nl; woffL = cA.offL; woffR = cA.offR;
+            whx = v.h1x; whvx = v.h1vx; w_stepped = true; twin_shift = 0;
+          }
           const unsigned sel = group_ballot<G>(shield_on && rank == r, gb);
           const bool has = sel != 0;
           const int ai = has ? (__ffs((int)sel) - 1) : 0;
           const int src = gb + ai;
           const double ex = shfl_d(v.x, src), ey = shfl_d(v.y, src);
           const int epk = shfl_i(v.lane | (nl_self << 4), src);
-          const Rel rl = relate(ex, ey, epk & 15, epk >> 4, live && has && a != ai, wx, wy, wh, wlane, wnl, woffL, woffR);
+          const double e_vx = shfl_d(v.v * cpsi, src);  // vehicle.velocity[0] of the ego
+          const Rel rl = relate(ex, ey, epk & 15, epk >> 4, live && has && a != ai, wx, wy, wh, wlane, wnl, woffL, woffR, hdv);
           int pos = 0;
           for_partners<G>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
@@ -801,6 +974,11 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
           unsigned f_ol = (in5 && rl.cls == 1) ? ((unsigned)pos << 5 | (unsigned)a << 1) : none;
           unsigned f_oa = (in5 && rl.cls == 2) ? ((unsigned)pos << 5 | (unsigned)a << 1 | (rl.cflag ? 1u : 0u)) : none;
           unsigned f_oar = (in5 && rl.cls == 3) ? ((unsigned)pos << 5 | (unsigned)a << 1) : none;
+          // digital-twin slot: every such HDV gets its record shifted, the LAST one in sorted order
+          // ends up in s_oa (the branch has no `is None` guard, :162-184) -> min over (15 - pos)
+          const bool is_twin = MIXED && in5 && rl.cls == 4;
+          if (is_twin) { whx = whx + 0.5 * e_vx; twin_shift = 1; }
+          unsigned f_tw = is_twin ? ((unsigned)(15 - pos) << 5 | (unsigned)a << 1) : none;
           unsigned w = f_ol | f_oa << 10 | f_oar << 20;
 #pragma unroll
           for (int m = 1; m < G; m <<= 1) {
@@ -808,8 +986,11 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
             unsigned m0 = min(w & 0x3FFu, o & 0x3FFu), m1 = min((w >> 10) & 0x3FFu, (o >> 10) & 0x3FFu),
                      m2 = min((w >> 20) & 0x3FFu, (o >> 20) & 0x3FFu);
             w = m0 | m1 << 10 | m2 << 20;
+            if (MIXED) f_tw = min(f_tw, (unsigned)__shfl_xor((int)f_tw, m, 64));
           }
           f_ol = w & 0x3FFu; f_oa = (w >> 10) & 0x3FFu; f_oar = (w >> 20) & 0x3FFu;
+          const bool has_tw = MIXED && f_tw != none;
+          if (has_tw) f_oa = f_tw & ~1u;  // s_oa = that HDV's (shifted) record; constrain_adj set below
           Neigh nb;
           nb.has_ol = f_ol != none; nb.has_oa = f_oa != none; nb.has_oar = f_oar != none;
           const int s_ol = gb + (nb.has_ol ? (int)((f_ol >> 1) & 15u) : 0);
@@ -824,11 +1005,14 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
           }
           nb.oar_x = shfl_d(wx, s_oar); nb.oar_vx = shfl_d(wvx, s_oar);
           nb.constrain_adj = MASS && nb.has_oa && (f_oa & 1u);
+          bool hss_collab = false;
+          if (has_tw) { nb.constrain_adj = MASS; hss_collab = !MASS; }  // cbf.constrain_adj = True (:181)
           if (!nb.has_ol) { nb.ol_acc = 0; nb.ol_g = 0; }
           if (!nb.has_oa) { nb.oa_acc = 0; nb.oa_g = 0; }
           if (!MASS) { nb.ol_acc = kCbfAccLo; nb.oa_acc = kCbfAccLo; }
           obstacle_override<MASS>(nb, v.x, v.y);
-          const ShieldOut s1 = shield_eval<MASS>(c, v, cpsi, offL, offR, nb);
+          ShieldOut s1 = shield_eval<MASS>(c, v, cpsi, offL, offR, nb);
+          if (hss_collab) s1.flags |= MM_FLAG_IS_COLLABORATING;  // vehicle.is_collaborating = cbf.constrain_adj
           if (has && a == ai && shield_on) {
             new_acc = s1.acc; veto = s1.veto; new_flags = s1.flags; qt = s1.qt;
             use_B = veto && needB;
@@ -840,6 +1024,8 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
             whx = v.h1x; whvx = v.h1vx; wlane = cc.lane; wnl = cc.nl; woffL = cc.offL; woffR = cc.offR;
           }
         }
+        // the in-place history edits persist in the record that becomes state_hist[-2] (stepped HDV)
+        if (MIXED && hdv && twin_shift != 0 && w_stepped) v.h1x = whx;
       }
     }
     // ---------------- commit Vehicle.step / MDPLCVehicle.step for every vehicle -------------------
@@ -854,13 +1040,16 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
       }
       v.x = cc.x; v.y = cc.y; v.h = cc.h; v.v = nv; v.lane = cc.lane;
       if (LC) {
-        v.safe_steer = (SHIELDED && shield_on && veto) ? steerB : v.act_steer;
-        v.safe_acc = acc; v.gvx = cc.gvx;
-        v.h2x = v.h1x; v.h2vx = v.h1vx;  // log_step :187-201
+        if (!hdv) {
+          v.safe_steer = (SHIELDED && shield_on && veto) ? steerB : v.act_steer;
+          v.safe_acc = acc; v.gvx = cc.gvx;
+        }
+        v.h2x = v.h1x; v.h2vx = v.h1vx;  // log_step :187-201 (IDMVehicleHist: behavior.py:505-521)
         v.h1x = v.x; v.h1vx = v.v * cc.cpsi;
         if (v.hist_len < 2) v.hist_len++;
       }
-      if (SHIELDED) { cpsi = cc.cpsi; offL = cc.offL; offR = cc.offR; nl_self = cc.nl; }
+      if (SHIELDED || MIXED) cpsi = cc.cpsi;
+      if (SHIELDED) { offL = cc.offL; offR = cc.offR; nl_self = cc.nl; }
     }
 
     // ---------------- collisions (road.py:288-292, kinematics.py:175-209) ----------------------
@@ -912,15 +1101,15 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
       t[MM_T_QP_H3 * A] = qt.h3; t[MM_T_QP_D * A] = qt.d; t[MM_T_LC_MARGIN * A] = qt.margin;
     }
     // _is_terminal (merge_env_v1.py:168-172) breaks the sub-step loop (abstract.py:530)
-    const bool term = group_ballot<G>(v.present && (v.crashed || v.x < 0), gb) != 0 || steps >= c.T;
+    const bool term = group_ballot<G>(ctrl && (v.crashed || v.x < 0), gb) != 0 || steps >= c.T;
     if (term) env_active = false;
   }
 
   // ---------------- rewards / info (merge_env_v1.py:59-166, abstract.py:469-498) -----------------
-  const bool env_ok = n_veh > 0;
-  const unsigned crashed_bits = group_ballot<G>(v.present && v.crashed, gb);
+  const bool env_ok = n_ctrl > 0;
+  const unsigned crashed_bits = group_ballot<G>(ctrl && v.crashed, gb);
   const bool done = env_ok && (crashed_bits != 0 || steps >= c.T ||
-                               group_ballot<G>(v.present && v.x < 0, gb) != 0);
+                               group_ballot<G>(ctrl && v.x < 0, gb) != 0);
   const int nl = v.present ? next_lane(v.lane, v.x, v.y) : 0;
   // surrounding_vehicles lane sets (road.py:315-342), as bit sets over lane ids
   const unsigned allow_tbl[6] = {
@@ -944,12 +1133,14 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
   double hd = 60;  // _compute_headway_distance abstract.py:620-635
   double of_s = 0, or_s = 0, sf_s = 0, sr_s = 0;
   int of_i = -1, or_i = -1, sf_i = -1, sr_i = -1;  // own/side chain front & rear
+  unsigned hdv_bits = 0;                           // which vehicles of the env are HDVs
   for_partners<G>([&](auto mc) {
     constexpr int m = decltype(mc)::value;
     const int p = a ^ m;
     double px = dppx_d<m>(v.x);
     int pk = dppx_i<m>(v.present ? v.lane : 15);
     bool pp = pk != 15;
+    if (MIXED) hdv_bits |= (dppx_i<m>((int)hdv) != 0) ? (1u << p) : 0u;
     if (pp && pk == v.lane && px > v.x) { double dd = px - v.x; if (dd < hd) hd = dd; }
     if (pp && v.lane != MM_LANE_BC1 && pk == nl && px > v.x) { double dd = px - v.x; if (dd < hd) hd = dd; }
     const bool in_own = pp && ((allow_own >> pk) & 1u), in_side = pp && ((allow_side >> pk) & 1u);
@@ -961,7 +1152,7 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
   });
   // _agent_reward merge_env_v1.py:64-89
   double local = 0;
-  if (v.present) {
+  if (ctrl) {
     double scaled = 0 + div_c((v.v - c.rs_lo) * (1 - 0), c.rs_span, c.rs_ispan);
     double merging = 0;
     if (v.lane == MM_LANE_BC1) { double t = v.x - 420; merging = -mmm_exp(MM_DIVC(-(t * t), 1000.0)); }
@@ -977,25 +1168,28 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     const int i_fr = on_main ? sf_i : of_i, i_rr = on_main ? sr_i : or_i;
     const double r_fl = shfl_d(local, gb + (i_fl < 0 ? 0 : i_fl)), r_fr = shfl_d(local, gb + (i_fr < 0 ? 0 : i_fr));
     const double r_rl = shfl_d(local, gb + (i_rl < 0 ? 0 : i_rl)), r_rr = shfl_d(local, gb + (i_rr < 0 ? 0 : i_rr));
+    auto is_mdp = [&](int j) { return j >= 0 && !((hdv_bits >> j) & 1u); };  // isinstance(v, MDPVehicle) :121
     double sum = 0;
     int cnt = 0;
-    if (i_fl >= 0) { sum += r_fl; cnt++; }
-    if (i_fr >= 0) { sum += r_fr; cnt++; }
+    if (is_mdp(i_fl)) { sum += r_fl; cnt++; }
+    if (is_mdp(i_fr)) { sum += r_fr; cnt++; }
     sum += local; cnt++;
-    if (i_rl >= 0) { sum += r_rl; cnt++; }
-    if (i_rr >= 0) { sum += r_rr; cnt++; }
+    if (is_mdp(i_rl)) { sum += r_rl; cnt++; }
+    if (is_mdp(i_rr)) { sum += r_rr; cnt++; }
     regional = sum / cnt;
   }
   // env-level sums in creation order (Python sum / += order)
-  double rsum = 0, ssum = 0;
+  double rsum = 0, ssum = 0, tsum = 0;
   for (int q = 0; q < st.N; q++) {
     const double lr = shfl_d(local, gb + q), sp = shfl_d(v.v, gb + q);
-    if ((present_bits >> q) & 1u) { rsum += lr; ssum += sp; }
+    if ((ctrl_bits >> q) & 1u) { rsum += lr; ssum += sp; }
+    if ((present_bits >> q) & 1u) tsum += sp;  // traffic_speed over road.vehicles (:147-151)
   }
-  const double reward = env_ok ? rsum / n_veh : 0, avg_speed = env_ok ? ssum / n_veh : 0;
+  const double reward = env_ok ? rsum / n_ctrl : 0, avg_speed = env_ok ? ssum / n_ctrl : 0;
+  const double traffic_speed = env_ok ? tsum / n_veh : 0;
   // _compute_min_time_headway merge_env_v1.py:373-386
   double th = INFINITY;
-  if (v.present) {
+  if (ctrl) {
     double h2d = hd;
     if (fabs(kObstY - v.y) <= 2 && kObstX > v.x) { double dd = kObstX - v.x; if (dd < h2d) h2d = dd; }
     h2d = h2d - kVehLength;
@@ -1006,13 +1200,13 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
   double merge_pct = __builtin_nan("");
   if (done) {
     const int n_rem = __popc(group_ballot<G>(
-        v.present && (v.lane == MM_LANE_BC1 || v.lane == MM_LANE_KB0 || v.lane == MM_LANE_JK0), gb));
+        ctrl && (v.lane == MM_LANE_BC1 || v.lane == MM_LANE_KB0 || v.lane == MM_LANE_JK0), gb));
     merge_pct = n_merge > 0 ? (double)(n_merge - n_rem) / n_merge * 100 : 100.0;
   }
   if (valid) {
-    if (out.agents_rewards) out.agents_rewards[i] = v.present ? local : 0;
-    if (out.regional_rewards) out.regional_rewards[i] = v.present ? regional : 0;
-    if (out.agents_dones) out.agents_dones[i] = v.present ? (uint8_t)(v.crashed || steps >= c.T || v.x < 0) : 1;
+    if (out.agents_rewards) out.agents_rewards[i] = ctrl ? local : 0;
+    if (out.regional_rewards) out.regional_rewards[i] = ctrl ? regional : 0;
+    if (out.agents_dones) out.agents_dones[i] = ctrl ? (uint8_t)(v.crashed || steps >= c.T || v.x < 0) : 1;
     if (out.crashed) out.crashed[i] = v.present ? (uint8_t)v.crashed : 0;
     if (out.agents_info) {
       out.agents_info[i * 3 + 0] = v.present ? v.x : 0;
@@ -1024,7 +1218,7 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     if (out.reward) out.reward[e] = reward;
     if (out.done) out.done[e] = (uint8_t)done;
     if (out.average_speed) out.average_speed[e] = avg_speed;
-    if (out.traffic_speed) out.traffic_speed[e] = avg_speed;  // CAV-only traffic: road.vehicles == controlled
+    if (out.traffic_speed) out.traffic_speed[e] = traffic_speed;
     if (out.min_headway) out.min_headway[e] = min_headway;
     if (out.merge_percent) out.merge_percent[e] = merge_pct;
   }
@@ -1034,7 +1228,7 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     if (threadIdx.x < 8) s_m[threadIdx.x] = threadIdx.x == 7 ? INFINITY : 0.0;
     __syncthreads();
     if (e < st.E && a == 0 && env_ok) {
-      atomicAdd(&s_m[0], reward); atomicAdd(&s_m[2], avg_speed); atomicAdd(&s_m[3], avg_speed);
+      atomicAdd(&s_m[0], reward); atomicAdd(&s_m[2], avg_speed); atomicAdd(&s_m[3], traffic_speed);
       atomicAdd(&s_m[4], 1.0);
       if (done) { atomicAdd(&s_m[1], crashed_bits ? 1.0 : 0.0); atomicAdd(&s_m[5], merge_pct); atomicAdd(&s_m[6], 1.0); }
       atomic_min_d(&s_m[7], min_headway);
@@ -1049,7 +1243,7 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     Veh nv;
     memset(&nv, 0, sizeof nv);
     int nm = 0;
-    if (valid && v.present) nm = spawn_vehicle(nv, a, n_veh, seed, (uint32_t)episode);
+    if (valid && v.present) nm = spawn_vehicle(nv, a, n_ctrl, n_veh - n_ctrl, seed, (uint32_t)episode);
     if (valid && v.present) v = nv;
     n_merge = shfl_i(nm, gb);
     steps = 0; time = 0; episode += 1;
@@ -1083,12 +1277,15 @@ __global__ __launch_bounds__(256) void reset_kernel(DevCfg c, DevState st, int m
       if (seeds_in && a == 0) st.seeds[e] = seeds_in[e];
       const uint64_t seed = seeds_in ? seeds_in[e] : st.seeds[e];
       int nm = 0;
-      if (valid) { nm = spawn_vehicle(v, a, st.N, seed, (uint32_t)episode); st.B[MM_B_KIND * st.A + i] = 1; }
+      if (valid) {
+        nm = spawn_vehicle(v, a, st.N - c.n_hdv, c.n_hdv, seed, (uint32_t)episode);
+        st.B[MM_B_KIND * st.A + i] = (uint8_t)v.kind;
+      }
       n_merge = shfl_i(nm, gb);
       episode += 1;
     } else {
       if (valid && v.present) init_vehicle(v);
-      n_merge = __popc(group_ballot<G>(valid && v.present && (v.lane == MM_LANE_JK0 || v.lane == MM_LANE_KB0), gb));
+      n_merge = __popc(group_ballot<G>(valid && v.kind == 1 && (v.lane == MM_LANE_JK0 || v.lane == MM_LANE_KB0), gb));
     }
     if (valid && v.present) store_veh(st, i, v);
     if (a == 0) {
@@ -1152,6 +1349,7 @@ static int check_cfg(const MMConfig *c, int N, char *err) {
   if (c->policy_frequency <= 0 || c->simulation_frequency < c->policy_frequency ||
       c->simulation_frequency / c->policy_frequency > 3) { snprintf(err, 256, "unsupported frequencies"); return MM_ERR_INVALID_ARG; }
   if (N > 12) { snprintf(err, 256, "N=%d exceeds the 6+6 spawn slots", N); return MM_ERR_INVALID_ARG; }
+  if (c->n_hdv < 0 || c->n_hdv >= N) { snprintf(err, 256, "n_hdv=%d must leave at least one controlled vehicle of N=%d", c->n_hdv, N); return MM_ERR_INVALID_ARG; }
   return MM_OK;
 }
 
@@ -1201,7 +1399,7 @@ static DevCfg dev_cfg(const MMHandle h) {
   d.env_kind = c.env_kind; d.shield = c.env_kind == MM_ENV_V1 ? c.shield : MM_SHIELD_NONE;
   d.nsub = c.simulation_frequency / c.policy_frequency; d.T = c.duration * c.policy_frequency;
   d.action_masking = c.action_masking; d.auto_reset = c.auto_reset; d.obs_f64 = c.obs_f64; d.N = h->N; d.E = h->E;
-  d.debug_flags = c.debug_flags;
+  d.debug_flags = c.debug_flags; d.n_hdv = c.n_hdv;
   d.dt = 1.0 / c.simulation_frequency;
   d.collision_reward = c.collision_reward; d.high_speed_reward = c.high_speed_reward;
   d.headway_cost = c.headway_cost; d.headway_time = c.headway_time; d.merging_lane_cost = c.merging_lane_cost;
@@ -1263,21 +1461,28 @@ extern "C" int32_t mm_observe(MMHandle h, void *obs, uint8_t *avail, MMStream st
   return launch_reset(h, 2, nullptr, nullptr, obs, avail, stream);
 }
 
-template <int G, int KIND, int SHIELD>
+template <int G, int KIND, int SHIELD, bool MIXED>
 static void launch_step_t(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   const long long threads = (long long)h->E * G;
   const unsigned grid = (unsigned)((threads + 255) / 256);
-  hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), actions,
-                     *out, h->metrics);
+  hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, MIXED>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h),
+                     actions, *out, h->metrics);
 }
+template <int G, bool MIXED>
+static void launch_step_m(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+  if (h->cfg.env_kind == MM_ENV_V0) { launch_step_t<G, MM_ENV_V0, MM_SHIELD_NONE, MIXED>(h, actions, out, s); return; }
+  switch (h->cfg.shield) {
+    case MM_SHIELD_HSS: launch_step_t<G, MM_ENV_V1, MM_SHIELD_HSS, MIXED>(h, actions, out, s); break;
+    case MM_SHIELD_MASS: launch_step_t<G, MM_ENV_V1, MM_SHIELD_MASS, MIXED>(h, actions, out, s); break;
+    default: launch_step_t<G, MM_ENV_V1, MM_SHIELD_NONE, MIXED>(h, actions, out, s);
+  }
+}
+// mixed traffic (cfg.n_hdv > 0) runs the kernels that carry the IDM/MOBIL code; CAV-only batches
+// keep the leaner instantiation
 template <int G>
 static void launch_step_g(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
-  if (h->cfg.env_kind == MM_ENV_V0) { launch_step_t<G, MM_ENV_V0, MM_SHIELD_NONE>(h, actions, out, s); return; }
-  switch (h->cfg.shield) {
-    case MM_SHIELD_HSS: launch_step_t<G, MM_ENV_V1, MM_SHIELD_HSS>(h, actions, out, s); break;
-    case MM_SHIELD_MASS: launch_step_t<G, MM_ENV_V1, MM_SHIELD_MASS>(h, actions, out, s); break;
-    default: launch_step_t<G, MM_ENV_V1, MM_SHIELD_NONE>(h, actions, out, s);
-  }
+  if (h->cfg.n_hdv > 0) launch_step_m<G, true>(h, actions, out, s);
+  else launch_step_m<G, false>(h, actions, out, s);
 }
 
 extern "C" int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStream stream) {

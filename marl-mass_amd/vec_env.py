@@ -95,7 +95,7 @@ class BatchedMergeEnv(object):
         """env.config[k] = v after construction (run_mappo.py:145-171); CBFType globals via kw."""
         if config:
             self.config.update(config)
-        for k in ("cbf_eta", "cbf_tau", "auto_reset", "seed"):
+        for k in ("cbf_eta", "cbf_tau", "auto_reset", "seed", "n_hdv"):
             if k in kw:
                 setattr(self, k, kw[k])
         self._cfg = self._make_cfg()

@@ -39,7 +39,7 @@ def env_kwargs(meta):
     cfg = {"safety_guarantee": meta["shield"], "HEADWAY_TIME": meta["headway_time"],
            "action_masking": False}
     return dict(env_id=meta["env_id"], config=cfg, cbf_eta=meta["eta"], cbf_tau=meta["headway_time"],
-                obs_f64=True, trace=True)
+                obs_f64=True, trace=True, n_hdv=meta.get("n_hdv", 0))
 
 
 KNIFE_EDGE = 1e-9  # |LC margin| below this = the reference's own decision is rounding noise

@@ -49,6 +49,22 @@ def test_reset_matches_reference_drawn_counts(resets):
         np.testing.assert_array_equal(env._b.f64[:5, 0, :row["n"]].numpy().T, np.array(row["f"]))
 
 
+def test_reset_matches_reference_mixed_traffic(resets):
+    """Mixed traffic: CAV + HDV counts drawn, HDVs on the remaining spawn slots, IDM timers."""
+    for row in resets["mixed"]:
+        env = compat.MergeEnvCompat(row["env"], backend_factory=_factory)
+        env.config.update({"traffic_density": row["td"], "traffic_type": "mixed", "mixed_traffic": True,
+                           "safety_guarantee": "none"})
+        obs, _ = env.reset(is_training=False, testing_seeds=row["seed"])
+        n, n_all = row["n"], row["n_all"]
+        assert len(env.controlled_vehicles) == n and len(env.road.vehicles) == n_all and env.n_merge == row["n_merge"]
+        np.testing.assert_array_equal(env._b.f64[:5, 0, :n_all].numpy().T, np.array(row["f"]))
+        np.testing.assert_array_equal(env._b.u8[abi.B["KIND"], 0, :n_all].numpy(), np.array(row["kind"]))
+        hd = np.array(row["kind"]) == 2
+        np.testing.assert_allclose(env._b.f64[abi.F["G_VX"], 0, :n_all].numpy()[hd], np.array(row["timer"])[hd], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(obs, np.array(row["obs"]), rtol=0, atol=1e-12)
+
+
 def test_training_seed_increments():
     env = compat.MergeEnvCompat("merge-multi-agent-v1", backend_factory=_factory)
     env.config["traffic_type"] = "cav"
@@ -57,7 +73,8 @@ def test_training_seed_increments():
     assert env.seed == s0 + 1  # abstract.py:190
 
 
-@pytest.mark.parametrize("name", ["ep_v0_none_N4_s25", "ep_v1_mass_N8_s0", "ep_v1_hss_N4_s50"])
+@pytest.mark.parametrize("name", ["ep_v0_none_N4_s25", "ep_v1_mass_N8_s0", "ep_v1_hss_N4_s50", "mx_v1_mass_4c3h_s25",
+                                  "mx_v0_none_3c3h_s0"])
 def test_step_tuple_matches_golden(name):
     """The (obs, reward, done, info) tuple of MergeEnv.step through the adapter, free-running."""
     z, meta = load_episode(os.path.join(GOLDEN, name + ".npz"))
@@ -65,7 +82,7 @@ def test_step_tuple_matches_golden(name):
     env = compat.MergeEnvCompat(meta["env_id"], backend_factory=_factory)
     env.config.update({"safety_guarantee": meta["shield"], "HEADWAY_TIME": meta["headway_time"],
                        "action_masking": False, "traffic_type": "cav", "mixed_traffic": False})
-    env._num_vehicles = lambda num_CAV=0: (meta["n"], 0)
+    env._num_vehicles = lambda num_CAV=0: (meta["n"], meta.get("n_hdv", 0))
     obs, avail = env.reset(is_training=False, testing_seeds=meta["seed"])
     np.testing.assert_allclose(obs, z["obs0"], rtol=0, atol=1e-12)
     assert env.n_s == meta["n_s"] and env.T == 100 and len(env.controlled_vehicles) == meta["n"]

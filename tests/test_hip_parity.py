@@ -75,14 +75,22 @@ CASES = [
     ("merge-multi-agent-v1", "cbf-cav", 5, 128, 60, 0.03125, 0.5),   # ragged group (N < G)
     ("merge-multi-agent-v1", "cbf-cav", 11, 128, 60, 0.03125, 0.5),  # G = 16
     ("merge-multi-agent-v1", "cbf-avs_cint", 2, 128, 60, 0.5, 1.2),
+    # mixed traffic: (N total vehicles, of which n_hdv IDM/MOBIL HDVs) -- 8th field
+    ("merge-multi-agent-v0", "none", 6, 256, 60, 0.0, 1.2, 3),
+    ("merge-multi-agent-v1", "none", 8, 256, 60, 0.0, 0.5, 4),
+    ("merge-multi-agent-v1", "cbf-avs_cint", 7, 256, 110, 0.03125, 0.5, 3),
+    ("merge-multi-agent-v1", "cbf-cav", 8, 512, 110, 0.03125, 0.5, 4),
+    ("merge-multi-agent-v1", "cbf-cav", 11, 128, 110, 0.03125, 0.5, 5),
 ]
 
 
-@pytest.mark.parametrize("env_id,safety,N,E,steps,eta,tau", CASES)
-def test_random_rollout_vs_oracle(env_id, safety, N, E, steps, eta, tau):
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(x) for x in c))
+def test_random_rollout_vs_oracle(case):
     """Same seeds, same action tape, auto-reset on: every output of every step must agree."""
+    env_id, safety, N, E, steps, eta, tau = case[:7]
+    n_hdv = case[7] if len(case) > 7 else 0
     kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau}, cbf_eta=eta, cbf_tau=tau,
-              obs_f64=True, seed=1000, auto_reset=True)
+              obs_f64=True, seed=1000, auto_reset=True, n_hdv=n_hdv)
     gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
     og, ag = gpu.reset()
     oc, ac = cpu.reset()

@@ -317,8 +317,24 @@ def gen_reset():
             f, i = zip(*[_veh_snapshot(v) for v in env.road.vehicles])
             counts.append(dict(td=td, seed=seed, n=len(env.controlled_vehicles),
                                n_merge=int(env.n_merge), f=np.array(f)[:, :5].tolist()))
+    # mixed traffic: CAV and HDV counts drawn, HDVs spawned on the remaining slots (:298-362)
+    mixed = []
+    for env_id in ("merge-multi-agent-v0", "merge-multi-agent-v1"):
+        for td in (1, 2, 3):
+            for seed in (0, 25, 50):
+                env = gym.make(env_id)
+                env.config["traffic_density"] = td
+                env.config["traffic_type"] = "mixed"
+                env.config["mixed_traffic"] = True
+                env.config["safety_guarantee"] = "none"
+                obs, mask = env.reset(is_training=False, testing_seeds=seed)
+                f, i = zip(*[_veh_snapshot(v) for v in env.road.vehicles])
+                mixed.append(dict(env=env_id, td=td, seed=seed, n=len(env.controlled_vehicles),
+                                  n_all=len(env.road.vehicles), n_merge=int(env.n_merge),
+                                  f=np.array(f)[:, :5].tolist(), timer=np.nan_to_num(np.array(f)[:, 10]).tolist(),
+                                  kind=np.array(i)[:, 8].tolist(), obs=np.asarray(obs).tolist()))
     with open(os.path.join(OUT, "reset.json"), "w") as fh:
-        json.dump(dict(fixed=rows, drawn=counts), fh)
+        json.dump(dict(fixed=rows, drawn=counts, mixed=mixed), fh)
     print("reset.json: %d fixed-count resets, %d drawn-count resets" % (len(rows), len(counts)))
 
 
@@ -384,4 +400,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "reset":
+        os.makedirs(OUT, exist_ok=True)
+        gen_reset()
+    else:
+        main()
