@@ -1093,8 +1093,8 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
       double *t = out.trace + (long long)k * MM_T_COUNT * A + i;
       t[MM_T_X * A] = v.x; t[MM_T_Y * A] = v.y; t[MM_T_HEADING * A] = v.h; t[MM_T_SPEED * A] = v.v;
       t[MM_T_ACT_STEER * A] = v.act_steer; t[MM_T_ACT_ACC * A] = v.act_acc;
-      t[MM_T_SAFE_STEER * A] = LC ? v.safe_steer : v.act_steer;
-      t[MM_T_SAFE_ACC * A] = LC ? v.safe_acc : v.act_acc;
+      t[MM_T_SAFE_STEER * A] = (LC && !hdv) ? v.safe_steer : v.act_steer;
+      t[MM_T_SAFE_ACC * A] = (LC && !hdv) ? v.safe_acc : v.act_acc;
       t[MM_T_LANE * A] = v.lane; t[MM_T_TARGET_LANE * A] = v.tlane; t[MM_T_CRASHED * A] = v.crashed;
       t[MM_T_FLAGS * A] = v.flags; t[MM_T_QP_ROWS * A] = qt.rows; t[MM_T_QP_A * A] = qt.a;
       t[MM_T_QP_H0 * A] = qt.h0; t[MM_T_QP_H1 * A] = qt.h1; t[MM_T_QP_H2 * A] = qt.h2;
