@@ -134,7 +134,7 @@ typedef struct MMConfig {
   uint64_t seed;                /* base seed of the device RNG; env e uses seed + e unless seeds given */
   int32_t n_hdv;                /* device reset: the last n_hdv of the N vehicles are IDM/MOBIL HDVs
                                    (mixed traffic, merge_env_v1.py:298-362); 0 = CAV-only */
-  int32_t reserved1;
+  int32_t agent_reward;         /* config["agent_reward"] (merge_env_v1.py:439-474): 0 default, 1 srew, 2 mrew */
 } MMConfig;
 
 /*

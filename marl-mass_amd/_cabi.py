@@ -49,7 +49,7 @@ class MMConfig(C.Structure):
                 ("headway_cost", C.c_double), ("headway_time", C.c_double),
                 ("merging_lane_cost", C.c_double), ("reward_speed_lo", C.c_double),
                 ("reward_speed_hi", C.c_double), ("cbf_eta", C.c_double), ("cbf_tau", C.c_double),
-                ("seed", C.c_uint64), ("n_hdv", C.c_int32), ("reserved1", C.c_int32)]
+                ("seed", C.c_uint64), ("n_hdv", C.c_int32), ("agent_reward", C.c_int32)]
 
 
 class MMStepOut(C.Structure):
@@ -118,6 +118,8 @@ def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs
     c.cbf_tau = float(config["HEADWAY_TIME"] if cbf_tau is None else cbf_tau)
     c.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     c.n_hdv = int(n_hdv)
+    ar = config.get("agent_reward", "default") if c.env_kind == ENV_V1 else "default"
+    c.agent_reward = {"srew": 1, "mrew": 2}.get(ar, 0)  # anything else falls back to the default reward (:446)
     return c
 
 

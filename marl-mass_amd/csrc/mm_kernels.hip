@@ -31,7 +31,8 @@ struct DevCfg {
   int env_kind, shield, nsub, T, action_masking, auto_reset, obs_f64, N, E, debug_flags, n_hdv;
   double dt, collision_reward, high_speed_reward, headway_cost, headway_time, merging_lane_cost;
   double rs_lo, rs_hi, eta, tau;
-  double inv_dt, rs_span, rs_ispan;  // host-computed reciprocals for div_c (correctly rounded 1/d)
+  double inv_dt, rs_span, rs_ispan, rs_span2, rs_ispan2;  // host-computed reciprocals for div_c (correctly rounded 1/d)
+  int agent_reward;
 };
 struct DevState {
   double *F;
@@ -1153,10 +1154,18 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
   // _agent_reward merge_env_v1.py:64-89
   double local = 0;
   if (ctrl) {
-    double scaled = 0 + div_c((v.v - c.rs_lo) * (1 - 0), c.rs_span, c.rs_ispan);
+    // default reward, or MergeEnvLCMARL's "srew" / "mrew" variants (merge_env_v1.py:439-474)
+    const bool xrew = LC && c.agent_reward != 0, is_mrew = c.agent_reward == 2;
+    const bool half = xrew && is_mrew && (v.flags & MM_FLAG_IS_COLLABORATING);  // halved speed range
+    double scaled = 0 + (half ? div_c((v.v - c.rs_lo) * (1 - 0), c.rs_span2, c.rs_ispan2)
+                              : div_c((v.v - c.rs_lo) * (1 - 0), c.rs_span, c.rs_ispan));
     double merging = 0;
-    if (v.lane == MM_LANE_BC1) { double t = v.x - 420; merging = -mmm_exp(MM_DIVC(-(t * t), 1000.0)); }
+    if (v.lane == MM_LANE_BC1 && (!(xrew && is_mrew) || (v.flags & MM_FLAG_IS_LC_SAFE))) {
+      double t = v.x - 420;
+      merging = -mmm_exp(MM_DIVC(-(t * t), 1000.0));
+    }
     double hc = v.v > 0 ? mmm_log(hd / (c.headway_time * v.v)) : 0;
+    if (xrew) hc = -1 * hc;  // srew / mrew flip the sign of the headway term (:465-466)
     local = c.collision_reward * (-1 * v.crashed) + (c.high_speed_reward * clipd(scaled, 0, 1)) +
             c.merging_lane_cost * merging + c.headway_cost * (hc < 0 ? hc : 0);
   }
@@ -1405,6 +1414,8 @@ static DevCfg dev_cfg(const MMHandle h) {
   d.headway_cost = c.headway_cost; d.headway_time = c.headway_time; d.merging_lane_cost = c.merging_lane_cost;
   d.rs_lo = c.reward_speed_lo; d.rs_hi = c.reward_speed_hi; d.eta = c.cbf_eta; d.tau = c.cbf_tau;
   d.inv_dt = 1.0 / d.dt; d.rs_span = d.rs_hi - d.rs_lo; d.rs_ispan = 1.0 / d.rs_span;
+  d.rs_span2 = (d.rs_lo + (d.rs_hi - d.rs_lo) / 2) - d.rs_lo; d.rs_ispan2 = 1.0 / d.rs_span2;  // mrew, collaborating
+  d.agent_reward = c.env_kind == MM_ENV_V1 ? c.agent_reward : 0;
   return d;
 }
 static DevState dev_state(const MMHandle h) {

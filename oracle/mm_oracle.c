@@ -881,6 +881,20 @@ static double compute_headway_distance(const Env *e, int i) {
 /* merge_env_v1.py:64-89 (v1 "default" agent_reward delegates here, :446-447) */
 static double agent_reward(const MMConfig *cfg, const Env *e, int i) {
   const Veh *v = &e->v[i];
+  if (cfg->env_kind == MM_ENV_V1 && cfg->agent_reward != 0) {
+    /* MergeEnvLCMARL._agent_reward, "srew" / "mrew" (merge_env_v1.py:439-474) */
+    const int is_mrew = cfg->agent_reward == 2;
+    double lo = cfg->reward_speed_lo, hi = cfg->reward_speed_hi;
+    if ((v->flags & MM_FLAG_IS_COLLABORATING) && is_mrew) hi = lo + (hi - lo) / 2;
+    double scaled = 0 + (v->speed - lo) * (1 - 0) / (hi - lo);
+    double merging2 = 0;
+    if (v->lane == MM_LANE_BC1 && (!is_mrew || (v->flags & MM_FLAG_IS_LC_SAFE)))
+      merging2 = -m_exp(-m_sq(v->x - 420) / (10 * 100));
+    double hd2 = compute_headway_distance(e, i);
+    double hc2 = v->speed > 0 ? -1 * m_log(hd2 / (cfg->headway_time * v->speed)) : 0;
+    return cfg->collision_reward * (-1 * v->crashed) + (cfg->high_speed_reward * clipd(scaled, 0, 1)) +
+           cfg->merging_lane_cost * merging2 + cfg->headway_cost * (hc2 < 0 ? hc2 : 0);
+  }
   double scaled_speed = 0 + (v->speed - cfg->reward_speed_lo) * (1 - 0) /
                                 (cfg->reward_speed_hi - cfg->reward_speed_lo);
   double merging = 0;

@@ -25,8 +25,8 @@ FLOAT_TOL = 1e-5  # north_star: "within 1e-5 on float state"
 
 def episode_files(pattern="*_*.npz"):
     """ep_*: random / idle tapes from reference spawns; sc_*: scripted crash scenarios (test/cbf);
-    mx_*: mixed traffic (CAVs + IDM/MOBIL HDVs)."""
-    return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern)) if os.path.basename(f)[:3] in ("ep_", "sc_", "mx_"))
+    mx_*: mixed traffic (CAVs + IDM/MOBIL HDVs); rw_*: srew / mrew agent rewards."""
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern)) if os.path.basename(f)[:3] in ("ep_", "sc_", "mx_", "rw_"))
 
 
 def load_episode(path):
@@ -37,7 +37,7 @@ def load_episode(path):
 
 def env_kwargs(meta):
     cfg = {"safety_guarantee": meta["shield"], "HEADWAY_TIME": meta["headway_time"],
-           "action_masking": False}
+           "action_masking": False, "agent_reward": meta.get("agent_reward", "default")}
     return dict(env_id=meta["env_id"], config=cfg, cbf_eta=meta["eta"], cbf_tau=meta["headway_time"],
                 obs_f64=True, trace=True, n_hdv=meta.get("n_hdv", 0))
 

@@ -81,6 +81,9 @@ CASES = [
     ("merge-multi-agent-v1", "cbf-avs_cint", 7, 256, 110, 0.03125, 0.5, 3),
     ("merge-multi-agent-v1", "cbf-cav", 8, 512, 110, 0.03125, 0.5, 4),
     ("merge-multi-agent-v1", "cbf-cav", 11, 128, 110, 0.03125, 0.5, 5),
+    # alternate agent rewards -- 9th field
+    ("merge-multi-agent-v1", "cbf-cav", 8, 256, 110, 0.03125, 0.5, 0, "mrew"),
+    ("merge-multi-agent-v1", "cbf-avs_cint", 6, 256, 110, 0.03125, 0.5, 2, "srew"),
 ]
 
 
@@ -89,7 +92,9 @@ def test_random_rollout_vs_oracle(case):
     """Same seeds, same action tape, auto-reset on: every output of every step must agree."""
     env_id, safety, N, E, steps, eta, tau = case[:7]
     n_hdv = case[7] if len(case) > 7 else 0
-    kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau}, cbf_eta=eta, cbf_tau=tau,
+    agent_reward = case[8] if len(case) > 8 else "default"
+    kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau, "agent_reward": agent_reward},
+              cbf_eta=eta, cbf_tau=tau,
               obs_f64=True, seed=1000, auto_reset=True, n_hdv=n_hdv)
     gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
     og, ag = gpu.reset()

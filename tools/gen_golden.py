@@ -75,7 +75,7 @@ def _road_step_logged(self, dt):
 Road.step = _road_step_logged
 
 
-def make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=0):
+def make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=0, agent_reward="default"):
     """Mirror of how run_mappo.py:137-171 configures an env (values from the cited .ini files)."""
     CBFType.GAMMA_B = eta
     CBFType.TAU = headway_time
@@ -94,7 +94,7 @@ def make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=0):
     env.config["lateral_control"] = "steer"
     env.config["mixed_traffic"] = n_hdv > 0
     env.config["traffic_type"] = "mixed" if n_hdv > 0 else "cav"
-    env.config["agent_reward"] = "default"
+    env.config["agent_reward"] = agent_reward
     # BASELINE configs fix the vehicle count (N CAVs, 0 HDVs); the reference draws it at random.
     env._num_vehicles = lambda num_CAV=0: (n_cav, n_hdv)
     return env
@@ -116,9 +116,9 @@ def _place_vehicles(env, placement):
 
 
 def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta, p=None,
-                max_steps=100, scripted=None, placement=None, n_hdv=0):
+                max_steps=100, scripted=None, placement=None, n_hdv=0, agent_reward="default"):
     global _SUBSTEP_LOG
-    env = make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=n_hdv)
+    env = make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=n_hdv, agent_reward=agent_reward)
     obs0, mask0 = env.reset(is_training=False, testing_seeds=seed)
     if placement is not None:
         obs0 = _place_vehicles(env, placement)
@@ -171,7 +171,7 @@ def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta,
         qp_G[k, :g.shape[0]] = g
         qp_h[k, :h.shape[0]] = h
         qp_x[k] = x
-    meta = dict(env_id=env_id, shield=shield, n=n_cav, n_hdv=n_hdv, seed=seed, tape_seed=tape_seed,
+    meta = dict(env_id=env_id, shield=shield, n=n_cav, n_hdv=n_hdv, agent_reward=agent_reward, seed=seed, tape_seed=tape_seed,
                 headway_time=headway_time, eta=eta, n_merge=int(env.n_merge),
                 n_s=int(env.n_s), crashed=bool(env.is_crashed()), steps=t,
                 qp_solver="exact-KKT closed form (cvxopt 1.2.7 unavailable)")
@@ -395,6 +395,11 @@ def main():
         metas.append(run_episode("mx_v1_mass_%dc%dh_s%d" % (nc, nh, seed), v1, "cbf-cav", nc, seed, 41 + seed, 0.5, 0.03125, n_hdv=nh))
     lc = [0.3, 0.2, 0.3, 0.1, 0.1]
     metas.append(run_episode("mx_v1_mass_4c4h_lc_s100", v1, "cbf-cav", 4, 100, 7, 0.5, 0.03125, p=lc, n_hdv=4))
+    # (5) alternate agent rewards (marl_cav-heading-t_headway-cbf-*-srew.ini / -mrew.ini)
+    lc2 = [0.25, 0.3, 0.25, 0.1, 0.1]
+    metas.append(run_episode("rw_v1_hss_srew_N4_s0", v1, "cbf-avs_cint", 4, 0, 77, 0.5, 0.03125, p=lc2, agent_reward="srew"))
+    metas.append(run_episode("rw_v1_mass_mrew_N8_s25", v1, "cbf-cav", 8, 25, 78, 0.5, 0.03125, p=lc2, agent_reward="mrew"))
+    metas.append(run_episode("rw_v1_mass_mrew_3c3h_s50", v1, "cbf-cav", 3, 50, 79, 0.5, 0.03125, p=lc2, n_hdv=3, agent_reward="mrew"))
     with open(os.path.join(OUT, "index.json"), "w") as fh:
         json.dump(metas, fh, indent=1)
 
