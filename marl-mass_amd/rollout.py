@@ -1,0 +1,122 @@
+"""On-device rollout: the batched counterpart of MAPPO.interact / evaluation.
+
+The reference collects experience one env-step at a time on the host (marl/mappo.py:102-158): per
+agent a shared actor MLP forward, `np.random.choice` over the softmax, `env.step`, regional rewards
+scaled by `reward_scale`, and a discounted return bootstrapped from the critic when the rollout
+ends mid-episode (`_discount_reward`, :364-370).  Here the same quantities are produced for E
+envs at once with every tensor staying in HBM: observations come straight out of `mm_step`, the
+actor runs as batched GEMMs (rocBLAS/hipBLASLt through torch -- plain library GEMMs, which is what
+they are), sampling is `torch.multinomial`, and the discounting is a reversed scan over the
+rollout with episode boundaries taken from `done`.
+
+Networks mirror marl/single_agent/Model_common.py:5-41 (state -> 128 -> 128 -> n_a, log-softmax;
+critic takes the one-hot action after the first layer).
+"""
+import torch
+from torch import nn
+
+
+class ActorNetwork(nn.Module):
+    """Model_common.py:5-22."""
+
+    def __init__(self, state_dim, hidden_size, output_size):
+        super().__init__()
+        self.fc1 = nn.Linear(state_dim, hidden_size)
+        self.fc2 = nn.Linear(hidden_size, hidden_size)
+        self.fc3 = nn.Linear(hidden_size, output_size)
+
+    def forward(self, state):
+        out = torch.relu(self.fc1(state))
+        out = torch.relu(self.fc2(out))
+        return torch.log_softmax(self.fc3(out), dim=-1)
+
+
+class CriticNetwork(nn.Module):
+    """Model_common.py:25-41."""
+
+    def __init__(self, state_dim, action_dim, hidden_size, output_size=1):
+        super().__init__()
+        self.fc1 = nn.Linear(state_dim, hidden_size)
+        self.fc2 = nn.Linear(hidden_size + action_dim, hidden_size)
+        self.fc3 = nn.Linear(hidden_size, output_size)
+
+    def forward(self, state, action_one_hot):
+        out = torch.relu(self.fc1(state))
+        out = torch.relu(self.fc2(torch.cat([out, action_one_hot], dim=-1)))
+        return self.fc3(out)
+
+
+def discount_rewards(rewards, dones, final_value, gamma):
+    """`_discount_reward` (marl/mappo.py:364-370) over a batch.
+
+    rewards [T, E, N], dones [T, E] (episode ended AT step t), final_value [E, N] (bootstrap for the
+    envs whose last step did not end an episode; the reference uses 0 after `done`).
+    running = final; for t reversed: running = running * gamma + r[t]; a `done` at step t cuts the
+    chain coming from later steps (they belong to the next episode of that env slot)."""
+    T = rewards.shape[0]
+    out = torch.empty_like(rewards)
+    running = final_value.clone()
+    for t in range(T - 1, -1, -1):
+        running = torch.where(dones[t].bool().unsqueeze(-1), torch.zeros_like(running), running)
+        running = running * gamma + rewards[t]
+        out[t] = running
+    return out
+
+
+class DeviceRollout(object):
+    """MAPPO.interact for a whole env batch; see the module docstring."""
+
+    def __init__(self, env, actor, critic=None, roll_out_n_steps=100, reward_gamma=0.99, reward_scale=20.0,
+                 reward_type="regionalR", generator=None):
+        assert reward_type in ("regionalR", "global_R")  # marl/mappo.py:39
+        self.env, self.actor, self.critic = env, actor, critic
+        self.T, self.gamma, self.reward_scale, self.reward_type = roll_out_n_steps, reward_gamma, reward_scale, reward_type
+        self.generator = generator
+        self.n_a = env.n_a
+        self.obs, _ = env.reset()
+        self.obs = self.obs.clone()
+
+    @torch.no_grad()
+    def act(self, obs):
+        """exploration_action / action (marl/mappo.py:220-236): sample from softmax(actor(obs))."""
+        E, N, S = obs.shape
+        logp = self.actor(obs.reshape(E * N, S).float())
+        return torch.multinomial(logp.exp(), 1, generator=self.generator).view(E, N).to(torch.int32)
+
+    @torch.no_grad()
+    def interact(self):
+        """One rollout of `roll_out_n_steps` policy steps on every env (auto-reset on).
+        Returns states [T,E,N,S], actions [T,E,N], discounted returns [T,E,N], dones [T,E] and the
+        per-step info means the reference logs (average speed, min headway)."""
+        env, T = self.env, self.T
+        E, N, S = self.obs.shape
+        dev = self.obs.device
+        states = torch.empty(T, E, N, S, dtype=self.obs.dtype, device=dev)
+        actions = torch.empty(T, E, N, dtype=torch.int32, device=dev)
+        rewards = torch.empty(T, E, N, dtype=torch.float64, device=dev)
+        dones = torch.empty(T, E, dtype=torch.uint8, device=dev)
+        speed_sum = torch.zeros(E, dtype=torch.float64, device=dev)
+        min_headway = torch.full((E,), float("inf"), dtype=torch.float64, device=dev)
+        obs = self.obs
+        for t in range(T):
+            states[t] = obs
+            a = self.act(obs)
+            obs, global_reward, done, info = env.step(a)
+            actions[t] = a
+            rewards[t] = info["regional_rewards"] if self.reward_type == "regionalR" else global_reward.unsqueeze(-1).expand(E, N)
+            dones[t] = done
+            speed_sum += info["average_speed"]
+            min_headway = torch.minimum(min_headway, info["min_headway"])
+        self.obs = obs.clone()
+        # bootstrap value for envs still mid-episode (marl/mappo.py:147-150); 0 where the last step ended one
+        final_value = torch.zeros(E, N, dtype=torch.float64, device=dev)
+        if self.critic is not None:
+            fa = self.act(obs)
+            one_hot = torch.nn.functional.one_hot(fa.long(), self.n_a).float()
+            val = self.critic(obs.reshape(E * N, S).float(), one_hot.view(E * N, self.n_a)).view(E, N).double()
+            final_value = torch.where(dones[-1].bool().unsqueeze(-1), final_value, val)
+        if self.reward_scale > 0:
+            rewards = rewards / self.reward_scale  # :152-153
+        returns = discount_rewards(rewards, dones, final_value, self.gamma)
+        return {"states": states, "actions": actions, "returns": returns, "dones": dones,
+                "average_speed": speed_sum / T, "min_headway": min_headway}

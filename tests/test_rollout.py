@@ -1,0 +1,68 @@
+"""On-device rollout counterpart of MAPPO.interact (marl/mappo.py:102-158,364-370), on CPU with the
+oracle backend: returns must equal the reference's per-agent `_discount_reward` applied episode by
+episode to the same reward tape."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_env
+from marl_mass_amd.rollout import ActorNetwork, CriticNetwork, DeviceRollout, discount_rewards
+
+
+def _discount_reward(rewards, final_value, gamma):  # marl/mappo.py:364-370 semantics
+    out = np.zeros_like(rewards)
+    running = final_value
+    for t in reversed(range(len(rewards))):
+        running = running * gamma + rewards[t]
+        out[t] = running
+    return out
+
+
+def test_discount_matches_reference_per_episode():
+    rs = np.random.RandomState(0)
+    T, E, N = 37, 5, 3
+    r = rs.randn(T, E, N)
+    d = rs.rand(T, E) < 0.1
+    fv = rs.randn(E, N)
+    got = discount_rewards(torch.tensor(r), torch.tensor(d), torch.tensor(fv), 0.99).numpy()
+    for e in range(E):
+        for n in range(N):
+            t0 = 0
+            ends = [t for t in range(T) if d[t, e]] + ([T - 1] if not d[T - 1, e] else [])
+            for t1 in ends:
+                final = 0.0 if d[t1, e] else fv[e, n]
+                np.testing.assert_allclose(got[t0:t1 + 1, e, n], _discount_reward(r[t0:t1 + 1, e, n], final, 0.99),
+                                           rtol=1e-12, atol=1e-12)
+                t0 = t1 + 1
+
+
+@pytest.mark.parametrize("reward_type", ["regionalR", "global_R"])
+def test_interact_shapes_and_bookkeeping(reward_type):
+    torch.manual_seed(0)
+    E, N = 6, 4
+    env = oracle_env.OracleEnv(E, N, env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
+                               cbf_eta=0.03125, cbf_tau=0.5, seed=5, auto_reset=True)
+    actor, critic = ActorNetwork(env.n_s, 128, env.n_a), CriticNetwork(env.n_s, env.n_a, 128)
+    g = torch.Generator().manual_seed(1)
+    ro = DeviceRollout(env, actor, critic, roll_out_n_steps=110, reward_type=reward_type, generator=g)
+    out = ro.interact()
+    assert out["states"].shape == (110, E, N, env.n_s) and out["actions"].shape == (110, E, N)
+    assert out["returns"].shape == (110, E, N) and torch.isfinite(out["returns"]).all()
+    assert int(out["dones"].sum()) == E  # 100-step episodes under the shield: each env finished exactly once
+    assert (out["actions"] >= 0).all() and (out["actions"] < 5).all()
+    out2 = ro.interact()  # a second rollout continues from the carried observation
+    assert not torch.equal(out2["states"][0], out["states"][0])
+
+
+@pytest.mark.gpu
+def test_interact_on_gpu():
+    from marl_mass_amd import VecMergeEnv
+    E, N = 4096, 8
+    env = VecMergeEnv(E, N, config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5,
+                      seed=5, auto_reset=True)
+    actor = ActorNetwork(env.n_s, 128, env.n_a).cuda()
+    critic = CriticNetwork(env.n_s, env.n_a, 128).cuda()
+    ro = DeviceRollout(env, actor, critic, roll_out_n_steps=20)
+    out = ro.interact()
+    assert out["returns"].is_cuda and torch.isfinite(out["returns"]).all()
+    assert out["states"].shape == (20, E, N, 30)
