@@ -238,6 +238,26 @@ int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec,
                      const int32_t *rows, double *u_out, uint8_t *status, MMStream stream);
 
 /*
+ * safety_layer(safety_type, action, vehicle, dt, ...) (decentral_layer.py:767-817; call site
+ * safe_controller.py:242-250) for EVERY controlled vehicle at once, each evaluated independently on
+ * the CURRENT state with the nominal low-level action given (nothing is stepped, nothing is
+ * written to the state: the reference's side effects on the vehicle -- is_lc_safe,
+ * is_collaborating, collaborate_adj, the veto's target-lane reset -- come back as status bits).
+ * act_steer / act_acc / safe_steer / safe_acc: DEV double[E][N]; status: DEV uint8[E][N]
+ * (MM_ST_* bits; 0 = shield gated off as in safe_controller.py:232-239, action returned unchanged);
+ * margin: DEV double[E][N] LC margin or NULL.
+ */
+#define MM_ST_RAN 1u           /* the CBF ran (safe_status is not None) */
+#define MM_ST_IS_OPTIMAL 2u    /* status["is_optimal"] */
+#define MM_ST_IS_SAFE 4u       /* status["is_safe"]      h_lon(s)  >= -1e-6  (cbf.py:341-351) */
+#define MM_ST_IS_INVARIANT 8u  /* status["is_invariant"] h_lon(s') + (eta-1) h_lon(s) >= -1e-6 */
+#define MM_ST_IS_LC_SAFE 16u   /* vehicle.is_lc_safe: no lane-change veto */
+#define MM_ST_IS_COLLABORATING 32u
+#define MM_ST_COLLABORATE_ADJ 64u
+int32_t mm_shield_actions(MMHandle h, const double *act_steer, const double *act_acc, double *safe_steer,
+                          double *safe_acc, uint8_t *status, double *margin, MMStream stream);
+
+/*
  * Rollout metric accumulator (the only cross-GPU quantity): adds this step's
  * {sum reward, crashed episodes, sum average_speed, sum traffic_speed, env-steps, sum merge %,
  *  finished episodes} into metrics[0..6] and min-reduces min_headway into metrics[7].

@@ -28,6 +28,7 @@ T = {n: i for i, n in enumerate(T_PLANES)}
 FLAG_COLLABORATE_ADJ, FLAG_IS_LC_SAFE, FLAG_IS_COLLABORATING = 1, 2, 4
 HL_NONE = 255
 
+ST_RAN, ST_IS_OPTIMAL, ST_IS_SAFE, ST_IS_INVARIANT, ST_IS_LC_SAFE, ST_IS_COLLABORATING, ST_COLLABORATE_ADJ = 1, 2, 4, 8, 16, 32, 64
 MM_OK, MM_ERR_INVALID_ARG, MM_ERR_NOT_READY, MM_ERR_DEVICE, MM_ERR_QP_BOUNDS = 0, -1, -2, -3, -4
 
 # (from, to, id) lane tuples of the reference <-> lane ids (merge_env_v1.py:231-245)
@@ -128,7 +129,7 @@ class CLib(object):
 
     SYMBOLS = ["mm_abi_version", "mm_state_layout", "mm_create", "mm_destroy", "mm_set_config",
                "mm_reset", "mm_init_from_kinematics", "mm_observe", "mm_step", "mm_shield_qp",
-               "mm_set_metrics_buffer", "mm_last_error", "mm_math_eval"]
+               "mm_set_metrics_buffer", "mm_last_error", "mm_math_eval", "mm_shield_actions"]
 
     def __init__(self, path):
         if not os.path.exists(path):
@@ -150,6 +151,7 @@ class CLib(object):
         lib.mm_set_metrics_buffer.argtypes = [vp, vp]
         lib.mm_last_error.argtypes = [vp]
         lib.mm_math_eval.argtypes = [i32, i32, vp, vp, vp, vp]
+        lib.mm_shield_actions.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         lib.mm_last_error.restype = C.c_char_p
         for s in self.SYMBOLS:
             if s not in ("mm_abi_version", "mm_last_error"):

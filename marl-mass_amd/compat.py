@@ -343,13 +343,35 @@ def cbf_factory(cbf_type, solver=None, **kwargs):
 
 
 def safety_layer(safety_type, action, vehicle, dt, safe_dist="theadway", **kwargs):
-    """decentral_layer.py:767-817 signature.  In this engine the shield runs fused inside `step`
-    (per sub-step, front-to-back); a per-vehicle stand-alone evaluation on device state is exposed
-    through the trace of a step (MMStepOut.trace), not through Python objects."""
+    """decentral_layer.py:767-817: (safe_action, safe_diff, status) for one vehicle of a MergeEnvCompat.
+
+    `vehicle` is one of `env.controlled_vehicles`; `action` its nominal {"steering", "acceleration"}.
+    The evaluation runs on the device (`mm_shield_actions`) against the env's current state; unlike the
+    reference it has no side effects on the vehicle -- is_lc_safe / is_collaborating / collaborate_adj
+    are returned in `status` next to is_optimal / is_safe / is_invariant."""
     if safety_type not in ("hss", "av", "avs", "avs_cint", "mass", "cav"):
         raise ValueError("Undefined safety_type:{0}".format(safety_type))
     if safe_dist != "theadway":
         raise ValueError("safe_dist type {} not supported".format(safe_dist))
-    raise NotImplementedError(
-        "stand-alone safety_layer() on Python vehicle objects: use MergeEnvCompat.step (fused shield) "
-        "or cbf_factory(...).control_barrier for a single QP")
+    env = vehicle._env
+    want = abi.SHIELD_MASS if safety_type in ("mass", "cav") else abi.SHIELD_HSS
+    b = env._b
+    if b._cfg.shield != want:
+        raise ValueError("env is configured with safety_guarantee=%r; safety_type %r needs the matching env.config"
+                         % (env.config.get("safety_guarantee"), safety_type))
+    if abs(dt * b._cfg.simulation_frequency - 1.0) > 1e-12:
+        raise ValueError("dt must be 1 / simulation_frequency")
+    steer = torch.zeros(1, MAX_VEHICLES, dtype=torch.float64)
+    acc = torch.zeros(1, MAX_VEHICLES, dtype=torch.float64)
+    steer[0, vehicle.id], acc[0, vehicle.id] = float(action["steering"]), float(action["acceleration"])
+    s_s, s_a, st, _ = b.shield_actions(steer, acc)
+    bits = int(st[0, vehicle.id])
+    safe_action = {"acceleration": float(s_a[0, vehicle.id]), "steering": float(s_s[0, vehicle.id])}
+    if not bits & abi.ST_RAN:  # gated off like get_safe_action (safe_controller.py:229-239)
+        return dict(action), None, None
+    safe_diff = {"acceleration": safe_action["acceleration"] - action["acceleration"],
+                 "steering": safe_action["steering"] - action["steering"]}
+    status = {"is_optimal": float(bool(bits & abi.ST_IS_OPTIMAL)), "is_safe": float(bool(bits & abi.ST_IS_SAFE)),
+              "is_invariant": float(bool(bits & abi.ST_IS_INVARIANT)), "is_lc_safe": bool(bits & abi.ST_IS_LC_SAFE),
+              "is_collaborating": bool(bits & abi.ST_IS_COLLABORATING), "collaborate_adj": bool(bits & abi.ST_COLLABORATE_ADJ)}
+    return safe_action, safe_diff, status

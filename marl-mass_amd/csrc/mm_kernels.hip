@@ -491,6 +491,7 @@ struct Neigh {  // the three slots of multi_agent_state (:85-257) after the obst
 struct ShieldOut {
   double acc, us0;  // derived acceleration, u_safe[0]
   bool veto;        // "Avoiding lane change" (:501-506 / :739-744)
+  bool lon_safe, lon_invariant;  // CBF_AV.update_status cbf.py:341-351
   int flags;
   QpTrace qt;
 };
@@ -583,6 +584,12 @@ MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s
   else d = 0.0;
   d = fmin(fmax(d, -s.h2), s.h1);
   double us0 = s.u0 + d;
+  {  // update_status (cbf.py:341-351) on u_status = [u_safe (QP), u_ll[2:]]
+    const double hls_lon = s.px_lon + s.q_lon;
+    const double hlds_lon = s.px_lon + ((-s.g0) * us0 + s.g2 * u2) + s.q_lon;
+    o.lon_safe = hls_lon >= -1e-6;
+    o.lon_invariant = (hlds_lon + (eta - 1) * hls_lon) >= -1e-6;
+  }
   // is_lc_allowed (cbf.py:324-339)
   const double hlds_lona = s.px_lona + ((-s.g0) * us0 + s.g4 * u4) + s.q_lona;
   const double hlds_lonr = s.px_lonr + (s.g0 * us0 + (-s.g6) * s.u6) + s.q_lonr;
@@ -1305,6 +1312,108 @@ __global__ __launch_bounds__(256) void reset_kernel(DevCfg c, DevState st, int m
   observe<G, KIND>(c, v, a, gb, i, valid, obs, avail);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone safety_layer(...) for every controlled vehicle on the current state (mm_shield_actions)
+// ------------------------------------------------------------------------------------------------
+template <int G, int SHIELD>
+__global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, const double *__restrict__ act_steer,
+                                                     const double *__restrict__ act_acc, double *__restrict__ safe_steer,
+                                                     double *__restrict__ safe_acc, uint8_t *__restrict__ status,
+                                                     double *__restrict__ margin) {
+  constexpr bool MASS = (SHIELD == MM_SHIELD_MASS);
+  const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e = gtid / G;
+  const int a = (int)(gtid % G);
+  const bool valid = e < st.E && a < st.N;
+  const long long i = e * st.N + a;
+  Veh v;
+  load_veh(st, i, valid, v);
+  const bool hdv = v.kind == 2;
+  const bool ctrl = v.present && !hdv;
+  if (valid) { v.act_steer = act_steer[i]; v.act_acc = act_acc[i]; }
+  const bool on = ctrl && SHIELD != MM_SHIELD_NONE && v.hist_len >= 2;  // gate safe_controller.py:229-239
+  const double cpsi = v.present ? mmm_cos(v.h) : 1.0;
+  bool offL = false, offR = false;
+  int nl_self = 0;
+  if (v.present) {
+    corner_flags(v.x, v.y, v.h, v.lane, offL, offR);
+    nl_self = next_lane(v.lane, v.x, v.y);
+  }
+  // every other vehicle is seen in its CURRENT state: records [-2], last safe_action, g.vx as stored
+  double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY, k_tw = -1;
+  int j_ol = -1, j_oa = -1, j_oar = -1, j_tw = -1;
+  Neigh nb;
+  memset(&nb, 0, sizeof nb);
+  double tw_x = 0, tw_vx = 0;
+  double keys[G];
+  keys[0] = INFINITY;
+  const double evx_raw = v.v * cpsi;  // vehicle.velocity[0]
+  for_partners<G>([&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    const int p = a ^ m;
+    const double ox = dppx_d<m>(v.x), oy = dppx_d<m>(v.y), oh = dppx_d<m>(v.h);
+    const int opk = dppx_i<m>(v.lane | nl_self << 3 | (int)offL << 6 | (int)offR << 7 | (int)v.present << 8 | (int)hdv << 9);
+    const double ohx = dppx_d<m>(v.h2x), ohvx = dppx_d<m>(v.h2vx);
+    const double og = dppx_d<m>(hdv ? 1.0 : v.gvx), oacc = dppx_d<m>(hdv ? kCbfAccLo : v.safe_acc);
+    const double ovx = dppx_d<m>(v.v * cpsi);
+    const bool o_hdv = ((opk >> 9) & 1) != 0;
+    const Rel r = relate(v.x, v.y, v.lane, nl_self, ((opk >> 8) & 1) != 0, ox, oy, oh, opk & 7, (opk >> 3) & 7,
+                         ((opk >> 6) & 1) != 0, ((opk >> 7) & 1) != 0, o_hdv);
+    keys[m] = r.key;
+    if (r.cls == 1 && (r.key < k_ol || (r.key == k_ol && p < j_ol))) { k_ol = r.key; j_ol = p; nb.ol_x = ohx; nb.ol_vx = ohvx; nb.ol_g = og; nb.ol_acc = oacc; }
+    if (r.cls == 2 && (r.key < k_oa || (r.key == k_oa && p < j_oa))) { k_oa = r.key; j_oa = p; nb.oa_x = ohx; nb.oa_vx = ohvx; nb.oa_g = og; nb.oa_acc = oacc; nb.constrain_adj = r.cflag; }
+    if (r.cls == 3 && (r.key < k_oar || (r.key == k_oar && p < j_oar))) { k_oar = r.key; j_oar = p; nb.oar_x = ox; nb.oar_vx = ovx; }
+    // on-ramp HDV twin: the LAST one in sorted order wins the slot (:162-184); its record is read shifted
+    if (r.cls == 4 && (r.key > k_tw || (r.key == k_tw && p > j_tw))) { k_tw = r.key; j_tw = p; tw_x = ohx + 0.5 * evx_raw; tw_vx = ohvx; }
+  });
+  int pos_ol = 0, pos_oa = 0, pos_oar = 0, n_close = 0;
+#pragma unroll
+  for (int m = 1; m < G; m++) {
+    const int p = a ^ m;
+    pos_ol += (keys[m] < k_ol || (keys[m] == k_ol && p < j_ol)) ? 1 : 0;
+    pos_oa += (keys[m] < k_oa || (keys[m] == k_oa && p < j_oa)) ? 1 : 0;
+    pos_oar += (keys[m] < k_oar || (keys[m] == k_oar && p < j_oar)) ? 1 : 0;
+    n_close += keys[m] < INFINITY ? 1 : 0;
+  }
+  nb.has_ol = j_ol >= 0 && pos_ol < 5;
+  nb.has_oa = j_oa >= 0 && pos_oa < 5;
+  nb.has_oar = j_oar >= 0 && pos_oar < 5;
+  nb.constrain_adj = MASS && nb.has_oa && nb.constrain_adj;
+  bool hss_collab = false;
+  if (j_tw >= 0) {
+    // a twin beyond the 5 nearest does not count: re-select the last twin among the first five
+    int pos_tw = 0;
+#pragma unroll
+    for (int m = 1; m < G; m++) pos_tw += (keys[m] < k_tw || (keys[m] == k_tw && (a ^ m) < j_tw)) ? 1 : 0;
+    if (pos_tw < 5) {
+      nb.has_oa = true; nb.oa_x = tw_x; nb.oa_vx = tw_vx; nb.oa_acc = kCbfAccLo; nb.oa_g = 1.0;
+      nb.constrain_adj = MASS; hss_collab = !MASS;
+    }
+  }
+  if (!nb.has_ol) { nb.ol_acc = 0; nb.ol_g = 0; }
+  if (!nb.has_oa) { nb.oa_acc = 0; nb.oa_g = 0; }
+  if (!MASS) { nb.ol_acc = kCbfAccLo; nb.oa_acc = kCbfAccLo; }
+  obstacle_override<MASS>(nb, v.x, v.y);
+  ShieldOut so = shield_eval<MASS>(c, v, cpsi, offL, offR, nb);
+  if (hss_collab) so.flags |= MM_FLAG_IS_COLLABORATING;
+  if (valid) {
+    double ss = v.act_steer, sa = v.act_acc;
+    unsigned stt = 0;
+    if (on) {
+      sa = so.acc;
+      if (so.veto) ss = steering_control(v.x, v.y, v.h, v.v, v.lane);  // target_lane_index = lane_index (:501-506)
+      stt = MM_ST_RAN | MM_ST_IS_OPTIMAL | (so.lon_safe ? MM_ST_IS_SAFE : 0u) | (so.lon_invariant ? MM_ST_IS_INVARIANT : 0u) |
+            ((so.flags & MM_FLAG_IS_LC_SAFE) ? MM_ST_IS_LC_SAFE : 0u) |
+            ((so.flags & MM_FLAG_IS_COLLABORATING) ? MM_ST_IS_COLLABORATING : 0u) |
+            ((so.flags & MM_FLAG_COLLABORATE_ADJ) ? MM_ST_COLLABORATE_ADJ : 0u);
+    }
+    safe_steer[i] = ss; safe_acc[i] = sa;
+    if (status) status[i] = (uint8_t)stt;
+    if (margin) margin[i] = on ? so.qt.margin : __builtin_nan("");
+  }
+}
+
 // stand-alone batched shield QP (cbf.py:110-161): exact KKT point, one thread per QP
 __global__ void qp_kernel(int n, const double *__restrict__ G, const double *__restrict__ h,
                           const int32_t *__restrict__ rows, double *__restrict__ u, uint8_t *status) {
@@ -1516,6 +1625,38 @@ extern "C" int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *
 #endif
   hipError_t rc = hipGetLastError();
   return rc == hipSuccess ? MM_OK : hip_fail(h, rc, "step launch");
+}
+
+
+template <int G>
+static void launch_shield_g(MMHandle h, const double *as, const double *aa, double *ss, double *sa, uint8_t *stt,
+                            double *mg, hipStream_t s) {
+  const long long threads = (long long)h->E * G;
+  const unsigned grid = (unsigned)((threads + 255) / 256);
+  const int sh = h->cfg.env_kind == MM_ENV_V1 ? h->cfg.shield : MM_SHIELD_NONE;
+  if (sh == MM_SHIELD_MASS)
+    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_MASS>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), as, aa, ss, sa, stt, mg);
+  else if (sh == MM_SHIELD_HSS)
+    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_HSS>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), as, aa, ss, sa, stt, mg);
+  else
+    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_NONE>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), as, aa, ss, sa, stt, mg);
+}
+extern "C" int32_t mm_shield_actions(MMHandle h, const double *act_steer, const double *act_acc, double *safe_steer,
+                                     double *safe_acc, uint8_t *status, double *margin, MMStream stream) {
+  if (!h || !act_steer || !act_acc || !safe_steer || !safe_acc) return MM_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+#ifdef MM_ONLY_G8
+  launch_shield_g<8>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, s);
+#else
+  switch (group_size(h->N)) {
+    case 2: launch_shield_g<2>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, s); break;
+    case 4: launch_shield_g<4>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, s); break;
+    case 8: launch_shield_g<8>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, s); break;
+    default: launch_shield_g<16>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, s); break;
+  }
+#endif
+  hipError_t rc = hipGetLastError();
+  return rc == hipSuccess ? MM_OK : hip_fail(h, rc, "shield launch");
 }
 
 extern "C" int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec, const int32_t *rows,

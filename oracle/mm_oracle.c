@@ -91,6 +91,7 @@ typedef struct {
   double local_reward, regional_reward;
   /* trace of the last shield call */
   double qp_rows, qp_a, qp_h[4], qp_d, lc_margin;
+  int lon_safe, lon_invariant; /* CBF_AV.update_status cbf.py:341-351 */
 } Veh;
 
 typedef struct {
@@ -640,6 +641,12 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
   int rc = 0;
   if (u_safe0 - 0.001 > v_max || u_safe0 + 0.001 < v_min) rc = MM_ERR_QP_BOUNDS; /* cbf.py:87-96 */
 
+  { /* update_status (cbf.py:341-351) with u_status = [u_safe (QP), u_ll[2:]] */
+    double hls_lon = px_lon + q_lon;
+    double hlds_lon = px_lon + ((-g[0]) * u_safe0 + g[2] * u[2]) + q_lon;
+    veh->lon_safe = hls_lon >= -1e-6;
+    veh->lon_invariant = (hlds_lon + (eta - 1) * hls_lon) >= -1e-6;
+  }
   u_safe1 = veh->act_steer; /* :493 / :721 lateral control is not constrained */
   double um[8] = {u_safe0, u_safe1, u[2], u[3], u[4], u[5], u[6], u[7]}; /* u_safe_ma */
   int flags = veh->flags & MM_FLAG_COLLABORATE_ADJ;
@@ -1301,6 +1308,48 @@ int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStre
   if (h->metrics) {
     for (int k = 0; k < 7; k++) h->metrics[k] += m_sum[k];
     if (m_min < h->metrics[7]) h->metrics[7] = m_min;
+  }
+  return rc_all;
+}
+
+int32_t mm_shield_actions(MMHandle h, const double *act_steer, const double *act_acc, double *safe_steer,
+                          double *safe_acc, uint8_t *status, double *margin, MMStream stream) {
+  (void)stream;
+  if (!h || !act_steer || !act_acc || !safe_steer || !safe_acc) return MM_ERR_INVALID_ARG;
+  const MMConfig *cfg = &h->cfg;
+  const double dt = 1.0 / cfg->simulation_frequency;
+  int rc_all = MM_OK;
+#pragma omp parallel for schedule(static)
+  for (int64_t e_idx = 0; e_idx < h->E; e_idx++) {
+    Env e;
+    load_env(h, e_idx, &e);
+    const int64_t base = e_idx * h->N;
+    for (int a = 0; a < h->N; a++) {
+      const int64_t i = base + a;
+      safe_steer[i] = act_steer[i]; safe_acc[i] = act_acc[i];
+      if (status) status[i] = 0;
+      if (margin) margin[i] = NAN;
+      if (a >= e.n_ctrl) continue;
+      /* gate of get_safe_action (safe_controller.py:229-239) */
+      if (cfg->env_kind != MM_ENV_V1 || cfg->shield == MM_SHIELD_NONE || e.v[a].hist_len < 2) continue;
+      Env w = e; /* safety_layer mutates the vehicle (and an on-ramp HDV's record): work on a copy */
+      w.v[a].act_steer = act_steer[i]; w.v[a].act_acc = act_acc[i];
+      double acc, steer;
+      int rc = safety_layer(cfg, &w, a, dt, &acc, &steer);
+      if (rc) {
+#pragma omp critical
+        { rc_all = rc; snprintf(h->err, sizeof h->err, "Error in QP. Invalid accceleration (env %lld)", (long long)e_idx); }
+      }
+      safe_steer[i] = steer; safe_acc[i] = acc;
+      const int fl = w.v[a].flags;
+      if (status)
+        status[i] = (uint8_t)(MM_ST_RAN | MM_ST_IS_OPTIMAL | (w.v[a].lon_safe ? MM_ST_IS_SAFE : 0) |
+                              (w.v[a].lon_invariant ? MM_ST_IS_INVARIANT : 0) |
+                              ((fl & MM_FLAG_IS_LC_SAFE) ? MM_ST_IS_LC_SAFE : 0) |
+                              ((fl & MM_FLAG_IS_COLLABORATING) ? MM_ST_IS_COLLABORATING : 0) |
+                              ((fl & MM_FLAG_COLLABORATE_ADJ) ? MM_ST_COLLABORATE_ADJ : 0));
+      if (margin) margin[i] = w.v[a].lc_margin;
+    }
   }
   return rc_all;
 }

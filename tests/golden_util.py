@@ -26,7 +26,7 @@ FLOAT_TOL = 1e-5  # north_star: "within 1e-5 on float state"
 def episode_files(pattern="*_*.npz"):
     """ep_*: random / idle tapes from reference spawns; sc_*: scripted crash scenarios (test/cbf);
     mx_*: mixed traffic (CAVs + IDM/MOBIL HDVs); rw_*: srew / mrew agent rewards."""
-    return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern)) if os.path.basename(f)[:3] in ("ep_", "sc_", "mx_", "rw_"))
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern)) if os.path.basename(f)[:3] in ("ep_", "sc_", "mx_", "rw_", "sl_"))
 
 
 def load_episode(path):
@@ -228,3 +228,37 @@ def free_run(make_env, path):
     crashed = bool(out["crashed"].any())
     env.close()
     return steps, crashed, mh
+
+
+def check_safety_layer_probes(make_env, path, tol=1e-9):
+    """Stand-alone safety_layer(...) parity: the tape holds reference calls for every controlled vehicle at
+    the start of selected steps (tools/gen_golden.py:_probe_safety_layer); compare mm_shield_actions."""
+    z, meta = load_episode(path)
+    nc, n = meta["n"], meta["n"] + meta.get("n_hdv", 0)
+    kw = env_kwargs(meta)
+    kw["trace"] = False
+    env = make_env(E=1, N=n, **kw)
+    f0, i0 = z["init_f"], z["init_i"]
+    env.set_kinematics(f0[None, :, 0], f0[None, :, 1], f0[None, :, 2], f0[None, :, 3], n_merge=np.array([meta["n_merge"]]),
+                       kind=i0[None, :, SI["kind"]])
+    cum = np.concatenate([[0], np.cumsum(z["sub_count"])])
+    worst, checked = 0.0, 0
+    for k, t in enumerate(z["sl_t"]):
+        _force_state(env, z, meta, int(t), int(cum[t]))
+        steer = np.zeros((1, n)); acc = np.zeros((1, n))
+        steer[0, :nc], acc[0, :nc] = z["sl_act"][k, :, 0], z["sl_act"][k, :, 1]
+        s_s, s_a, st, mg = env.shield_actions(steer, acc)
+        s_s, s_a, st, mg = s_s[0, :nc].cpu().numpy(), s_a[0, :nc].cpu().numpy(), st[0, :nc].cpu().numpy(), mg[0, :nc].cpu().numpy()
+        ref_st = z["sl_status"][k]
+        for j in range(nc):
+            got = [bool(st[j] & b) for b in (abi.ST_IS_OPTIMAL, abi.ST_IS_SAFE, abi.ST_IS_INVARIANT, abi.ST_IS_LC_SAFE,
+                                             abi.ST_IS_COLLABORATING, abi.ST_COLLABORATE_ADJ)]
+            assert st[j] & abi.ST_RAN
+            if got != [bool(x) for x in ref_st[j]] or abs(s_s[j] - z["sl_safe"][k, j, 0]) > tol:
+                assert abs(mg[j]) < KNIFE_EDGE, (path, t, j, got, ref_st[j], mg[j])  # only the LC knife-edge may differ
+                continue
+            worst = max(worst, abs(s_s[j] - z["sl_safe"][k, j, 0]), abs(s_a[j] - z["sl_safe"][k, j, 1]))
+            checked += 1
+    assert checked >= 0.9 * len(z["sl_t"]) * nc and worst <= tol, (checked, worst)
+    env.close()
+    return worst, checked

@@ -136,3 +136,27 @@ def test_cbf_control_barrier_shim_matches_golden_qp():
     d = min(0.0, h0 / G[0, 0])
     d = min(max(d, -h[2]), h[1])
     assert abs(u_safe[0] - (u0 + d)) <= 1e-12
+
+
+def test_safety_layer_shim():
+    """compat.safety_layer(safety_type, action, vehicle, dt) -> (safe_action, safe_diff, status), reference signature."""
+    compat.CBFType.GAMMA_B, compat.CBFType.TAU = 0.03125, 0.5
+    env = compat.MergeEnvCompat("merge-multi-agent-v1", backend_factory=_factory)
+    env.config.update({"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5, "traffic_type": "cav", "traffic_density": 2})
+    env.reset(is_training=False, testing_seeds=3)
+    n = len(env.controlled_vehicles)
+    veh = env.controlled_vehicles[1]
+    act = {"steering": 0.01, "acceleration": 3.0}
+    # first two sub-steps of an episode: shield gated off -> action returned, diff / status None
+    sa, sd, st = compat.safety_layer("cav", act, veh, 1 / 15)
+    assert sa == act and sd is None and st is None
+    for _ in range(3):
+        env.step((1,) * n)
+    sa, sd, st = compat.safety_layer("cav", act, veh, 1 / 15)
+    assert set(sa) == {"acceleration", "steering"} and set(st) >= {"is_optimal", "is_safe", "is_invariant"}
+    assert abs(sd["acceleration"] - (sa["acceleration"] - act["acceleration"])) < 1e-15
+    assert sa["acceleration"] <= 6.0 + 1e-9  # within the acceleration bound of the QP
+    with pytest.raises(ValueError):
+        compat.safety_layer("avs_cint", act, veh, 1 / 15)  # env is configured for MASS
+    with pytest.raises(ValueError):
+        compat.safety_layer("cav", act, veh, 1 / 15, safe_dist="fixed")

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import oracle_env
-from golden_util import episode_files, free_run, load_episode, replay, FLOAT_TOL
+from golden_util import check_safety_layer_probes, episode_files, free_run, load_episode, replay, FLOAT_TOL
 from marl_mass_amd import VecMergeEnv, _cabi as abi
 
 pytestmark = pytest.mark.gpu
@@ -64,6 +64,32 @@ def test_crash_scenarios_free_running(path):
     assert (steps, crashed) == (meta["steps"], meta["crashed"])
     if meta["shield"] != "none":
         assert mh > 0.0
+
+
+@pytest.mark.parametrize("path", episode_files("sl_*.npz"), ids=lambda p: os.path.basename(p)[:-4])
+def test_standalone_safety_layer(path):
+    """mm_shield_actions on the GPU vs the reference's per-vehicle safety_layer(...) calls."""
+    worst, checked = check_safety_layer_probes(_gpu_env, path, tol=1e-9)
+    assert checked > 0
+
+
+def test_standalone_safety_layer_bits_vs_oracle():
+    """Same entry, random states: HIP == oracle (mode 1) bit for bit, MASS with HDVs."""
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
+              cbf_eta=0.03125, cbf_tau=0.5, seed=31, auto_reset=True, n_hdv=3)
+    E, N = 512, 8
+    gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
+    gpu.reset(); cpu.reset()
+    g = torch.Generator().manual_seed(3)
+    for t in range(30):
+        a = torch.randint(0, 5, (E, N), generator=g, dtype=torch.int32)
+        gpu.step(a.cuda()); cpu.step(a)
+        if t % 5 == 4:
+            steer = (torch.rand(E, N, dtype=torch.float64, generator=g) - 0.5) * 0.2
+            acc = (torch.rand(E, N, dtype=torch.float64, generator=g) - 0.5) * 12
+            rg, rc = gpu.shield_actions(steer, acc), cpu.shield_actions(steer, acc)
+            for x, y in zip(rg, rc):
+                assert torch.equal(x.cpu().nan_to_num(), y.nan_to_num()), t
 
 
 CASES = [

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_env
-from golden_util import GOLDEN, episode_files, free_run, load_episode, replay
+from golden_util import GOLDEN, check_safety_layer_probes, episode_files, free_run, load_episode, replay
 
 
 @pytest.fixture(scope="module")
@@ -127,3 +127,11 @@ def test_crash_scenarios_free_running(path):
         assert not crashed and steps == 100 and mh > 0.0
     else:
         assert crashed and steps < 100
+
+
+@pytest.mark.parametrize("path", episode_files("sl_*.npz"), ids=lambda p: os.path.basename(p)[:-4])
+def test_standalone_safety_layer(path):
+    """mm_shield_actions == the reference's safety_layer(...) called per vehicle on a copy of the env."""
+    oracle_env.set_math_mode(0)
+    worst, checked = check_safety_layer_probes(oracle_env.OracleEnv, path, tol=1e-10)
+    print(os.path.basename(path), "checked", checked, "worst", worst)

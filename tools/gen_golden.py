@@ -115,8 +115,32 @@ def _place_vehicles(env, placement):
     return np.asarray(obs).reshape((len(obs), -1))
 
 
+def _probe_safety_layer(env, shield, t, rng):
+    """Stand-alone reference calls safety_layer(safety_type, action, vehicle, dt, ...) (decentral_layer.py:767-817)
+    for every controlled vehicle at the start of step t, each on its own deep copy of the env (the call
+    has side effects).  Returns (t, actions[n,2], safe[n,2], status[n,6])."""
+    import copy
+    from highway_env.vehicle.safety.decentral_layer import safety_layer as ref_safety_layer
+    saved = cvxopt.solvers.log
+    cvxopt.solvers.log = None
+    acts, safes, stats = [], [], []
+    for k in range(len(env.controlled_vehicles)):
+        ec = copy.deepcopy(env)
+        veh = ec.controlled_vehicles[k]
+        action = {"steering": float(veh.action["steering"]) + float(rng.uniform(-0.02, 0.02)),
+                  "acceleration": float(rng.uniform(-6, 6))}
+        sa, sd, st = ref_safety_layer(safety_type=shield.split("-")[1], action=dict(action), vehicle=veh, dt=1 / 15,
+                                      road=ec.road, perception_dist=180, safe_dist="theadway")
+        acts.append([action["steering"], action["acceleration"]])
+        safes.append([sa["steering"], sa["acceleration"]])
+        stats.append([st["is_optimal"], st["is_safe"], st["is_invariant"], float(veh.is_lc_safe),
+                      float(veh.is_collaborating), float(veh.collaborate_adj)])
+    cvxopt.solvers.log = saved
+    return t, acts, safes, stats
+
+
 def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta, p=None,
-                max_steps=100, scripted=None, placement=None, n_hdv=0, agent_reward="default"):
+                max_steps=100, scripted=None, placement=None, n_hdv=0, agent_reward="default", probe_shield=False):
     global _SUBSTEP_LOG
     env = make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=n_hdv, agent_reward=agent_reward)
     obs0, mask0 = env.reset(is_training=False, testing_seeds=seed)
@@ -134,7 +158,10 @@ def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta,
                            "merge_percent", "action_mask", "qp_count")}
     done = False
     t = 0
+    probes = []
     while not done and t < max_steps:
+        if probe_shield and t >= 2 and t % 6 == 3:
+            probes.append(_probe_safety_layer(env, shield, t, rng))
         if scripted is not None:
             a = tuple(int(x) for x in scripted[min(t, len(scripted) - 1)])
         else:
@@ -190,7 +217,11 @@ def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta,
         average_speed=np.array(rec["average_speed"]), traffic_speed=np.array(rec["traffic_speed"]),
         min_headway=np.array(rec["min_headway"]), merge_percent=np.array(rec["merge_percent"]),
         action_mask=np.array(rec["action_mask"]), qp_count=np.array(rec["qp_count"], dtype=np.int32),
-        qp_rows=qp_rows, qp_G=qp_G, qp_h=qp_h, qp_x=qp_x)
+        qp_rows=qp_rows, qp_G=qp_G, qp_h=qp_h, qp_x=qp_x,
+        sl_t=np.array([p_[0] for p_ in probes], dtype=np.int32),
+        sl_act=np.array([p_[1] for p_ in probes], dtype=np.float64).reshape(len(probes), -1, 2),
+        sl_safe=np.array([p_[2] for p_ in probes], dtype=np.float64).reshape(len(probes), -1, 2),
+        sl_status=np.array([p_[3] for p_ in probes], dtype=np.float64).reshape(len(probes), -1, 6))
     print("%-40s steps=%3d crashed=%d qps=%d" % (name, t, meta["crashed"], len(qps)))
     return meta
 
