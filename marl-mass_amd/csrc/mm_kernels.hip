@@ -1341,11 +1341,11 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
     nl_self = next_lane(v.lane, v.x, v.y);
   }
   // every other vehicle is seen in its CURRENT state: records [-2], last safe_action, g.vx as stored
-  double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY, k_tw = -1;
-  int j_ol = -1, j_oa = -1, j_oar = -1, j_tw = -1;
+  double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
+  int j_ol = -1, j_oa = -1, j_oar = -1;
   Neigh nb;
   memset(&nb, 0, sizeof nb);
-  double tw_x = 0, tw_vx = 0;
+  unsigned tw_mask = 0;  // partners (by xor mask m) in the on-ramp HDV twin class
   double keys[G];
   keys[0] = INFINITY;
   const double evx_raw = v.v * cpsi;  // vehicle.velocity[0]
@@ -1364,8 +1364,7 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
     if (r.cls == 1 && (r.key < k_ol || (r.key == k_ol && p < j_ol))) { k_ol = r.key; j_ol = p; nb.ol_x = ohx; nb.ol_vx = ohvx; nb.ol_g = og; nb.ol_acc = oacc; }
     if (r.cls == 2 && (r.key < k_oa || (r.key == k_oa && p < j_oa))) { k_oa = r.key; j_oa = p; nb.oa_x = ohx; nb.oa_vx = ohvx; nb.oa_g = og; nb.oa_acc = oacc; nb.constrain_adj = r.cflag; }
     if (r.cls == 3 && (r.key < k_oar || (r.key == k_oar && p < j_oar))) { k_oar = r.key; j_oar = p; nb.oar_x = ox; nb.oar_vx = ovx; }
-    // on-ramp HDV twin: the LAST one in sorted order wins the slot (:162-184); its record is read shifted
-    if (r.cls == 4 && (r.key > k_tw || (r.key == k_tw && p > j_tw))) { k_tw = r.key; j_tw = p; tw_x = ohx + 0.5 * evx_raw; tw_vx = ohvx; }
+    if (r.cls == 4) tw_mask |= 1u << m;
   });
   int pos_ol = 0, pos_oa = 0, pos_oar = 0, n_close = 0;
 #pragma unroll
@@ -1381,12 +1380,27 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
   nb.has_oar = j_oar >= 0 && pos_oar < 5;
   nb.constrain_adj = MASS && nb.has_oa && nb.constrain_adj;
   bool hss_collab = false;
-  if (j_tw >= 0) {
-    // a twin beyond the 5 nearest does not count: re-select the last twin among the first five
-    int pos_tw = 0;
+  {
+    // on-ramp HDV twin (:162-184): among the twins within the 5 nearest, the LAST one in sorted order
+    // takes the adjacent slot (the branch has no `is None` guard); its record is read shifted
+    int m_best = 0, pos_best = -1;
 #pragma unroll
-    for (int m = 1; m < G; m++) pos_tw += (keys[m] < k_tw || (keys[m] == k_tw && (a ^ m) < j_tw)) ? 1 : 0;
-    if (pos_tw < 5) {
+    for (int m = 1; m < G; m++) {
+      if ((tw_mask >> m) & 1u) {
+        int pos = 0;
+#pragma unroll
+        for (int m2 = 1; m2 < G; m2++)
+          if (m2 != m) pos += (keys[m2] < keys[m] || (keys[m2] == keys[m] && (a ^ m2) < (a ^ m))) ? 1 : 0;
+        if (pos < 5 && pos > pos_best) { pos_best = pos; m_best = m; }
+      }
+    }
+    double tw_x = 0, tw_vx = 0;
+    for_partners<G>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      const double ohx = dppx_d<m>(v.h2x), ohvx = dppx_d<m>(v.h2vx);
+      if (m == m_best) { tw_x = ohx + 0.5 * evx_raw; tw_vx = ohvx; }
+    });
+    if (pos_best >= 0) {
       nb.has_oa = true; nb.oa_x = tw_x; nb.oa_vx = tw_vx; nb.oa_acc = kCbfAccLo; nb.oa_g = 1.0;
       nb.constrain_adj = MASS; hss_collab = !MASS;
     }
