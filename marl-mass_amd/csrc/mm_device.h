@@ -26,6 +26,11 @@ constexpr double kCbfAccLo = -12.5, kCbfAccHi = 6.0, kAdjBuffer = 2.0134; // cbf
 constexpr double kSineAmp = 3.25, kSinePuls = 2 * kPi / (2 * 100.0), kSinePhase = kPi / 2;
 constexpr double kObstX = 420.0, kObstY = 4.0;                            // merge_env_v1.py:247
 // controller.py:32-33 (np.sqrt(1 + 6.25) + 0.0075, np.arctan(0.4)) as correctly rounded doubles
+// sqrt-free forms of the two distance tests (np.linalg.norm = sqrt(dx*dx + dy*dy), correctly rounded and
+// monotone): sqrt(s) < 180  <=>  s < kT180 (the smallest double whose root rounds to >= 180), and
+// sqrt(s) > 5  <=>  s > kU5 (the largest double whose root rounds to <= 5).  The oracle keeps the sqrt.
+constexpr double kT180 = 0x1.fa3ffffffffffp+14;  // 32399.999999999996
+constexpr double kU5 = 0x1.9000000000001p+4;     // 25.000000000000004
 constexpr double kCornerLen = 2.7000824035672517;
 constexpr double kCornerAlpha = 0.3805063771123649;
 

@@ -43,6 +43,20 @@ struct DevState {
   int E, N;
 };
 
+// Diagnostic build only (-DMM_STAMPS): per-phase cycle sums (s_memtime) accumulated by lane 0 of each
+// wave into a __device__ array the host reads with mm_debug_read_stamps.  Never in the product build.
+#ifdef MM_STAMPS
+__device__ unsigned long long g_stamps[16];
+#define STAMP(k)                                                                         \
+  do {                                                                                   \
+    unsigned long long _t = __builtin_amdgcn_s_memtime();                                \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[k], _t - _t_last);                  \
+    _t_last = __builtin_amdgcn_s_memtime();                                              \
+  } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+
 struct Veh {
   double x, y, h, v, tspeed;
   double act_steer, act_acc, safe_steer, safe_acc, gvx;
@@ -241,11 +255,15 @@ MM_DEV Cand predict(const Veh &v, double steer, double dt) {
   return c;
 }
 
-// decentral_layer.py:23-39 is_adj_lane(vehicle, lane2) given vehicle.lane and its next_lane
+// decentral_layer.py:23-39 is_adj_lane(vehicle, lane2) given vehicle.lane and its next_lane.  Only road
+// (b,c) has two lanes, so "same road and ids differ by one" means the pair {bc0, bc1}: bc0 sees bc1
+// at -1 (to its right), bc1 sees bc0 at +1.
+MM_DEV int adj_pair(int l1, int l2) {
+  return (l1 == MM_LANE_BC0 && l2 == MM_LANE_BC1) ? -1 : ((l1 == MM_LANE_BC1 && l2 == MM_LANE_BC0) ? 1 : 0);
+}
 MM_DEV int adj_lane(int l1, int nl1, int l2) {
-  if (lane_road(l1) == lane_road(l2) && abs(lane_rid(l1) - lane_rid(l2)) == 1) return lane_rid(l1) - lane_rid(l2);
-  if (lane_road(nl1) == lane_road(l2) && abs(lane_rid(nl1) - lane_rid(l2)) == 1) return lane_rid(nl1) - lane_rid(l2);
-  return 0;
+  const int f = adj_pair(l1, l2);
+  return f != 0 ? f : adj_pair(nl1, l2);
 }
 
 struct QpTrace {
@@ -338,7 +356,7 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
     double px = dppx_d<m>(v.x), py = dppx_d<m>(v.y);
     bool pp = dppx_i<m>((int)v.present) != 0;
     double dx = px - v.x, dy = py - v.y;
-    bool close = pp && sqrt(dx * dx + dy * dy) < kPerception;
+    bool close = pp && (dx * dx + dy * dy) < kT180;  // norm < PERCEPTION_DISTANCE, sqrt-free
     key[m] = close ? fabs((px - sx) - (v.x - sx)) : INFINITY;
   });
   double row[4][F - 1];
@@ -629,24 +647,25 @@ struct Rel {
 };
 MM_DEV Rel relate(double ex, double ey, int elane, int enl, bool other, double ox, double oy, double oh, int olane,
                   int onl, bool ooffL, bool ooffR, bool o_hdv = false) {
+  // written with non-short-circuit logic on purpose: it runs once per (ego, partner) pair and should
+  // compile to compares and selects, not to exec-mask branches
   Rel r;
   const double dx = ox - ex, dy = oy - ey;
-  const bool close = other && sqrt(dx * dx + dy * dy) < kPerception;  // road.py:259-262
+  const bool close = other & ((dx * dx + dy * dy) < kT180);  // road.py:259-262 (norm < 180, sqrt-free)
   const double esx = lane_sx(elane);
   const double ld = (ox - esx) - (ex - esx);  // kinematics.py:161-173
   r.key = close ? fabs(ld) : INFINITY;
   const int v_a = adj_lane(elane, enl, olane), a_v = adj_lane(olane, onl, elane);
-  const bool appr = !(ld < 0) && fabs(dy) <= 3.5 && (dy < 0 ? oh > 0.037 : oh < -0.037);  // :46-57
-  const bool adj = !appr && (v_a != 0 || a_v != 0);
-  const bool same = (elane == olane) || (olane == enl);  // is_same_lane :15-20
-  r.cls = 0;
-  if (close) {
-    if (adj) r.cls = ld < 0 ? 3 : 2;
-    // :162-184 HDV on the merging lane next to an ego on ab0: "digital twin" slot (class 4)
-    else if (o_hdv && elane == MM_LANE_AB0 && olane == MM_LANE_KB0 && ld >= 0) r.cls = 4;
-    else if ((same || appr) && ld > 0) r.cls = 1;
-  }
-  r.cflag = (v_a == -1 || a_v == 1) ? ooffL : ooffR;  // :146-152 which front corner of `o`
+  const bool head = (dy < 0) ? (oh > 0.037) : (oh < -0.037);
+  const bool appr = (!(ld < 0)) & (fabs(dy) <= 3.5) & head;  // :46-57
+  const bool adj = (!appr) & ((v_a | a_v) != 0);
+  const bool same = (elane == olane) | (olane == enl);  // is_same_lane :15-20
+  // :162-184 HDV on the merging lane next to an ego on ab0: "digital twin" slot (class 4)
+  const bool twin = o_hdv & (!adj) & (elane == MM_LANE_AB0) & (olane == MM_LANE_KB0) & (ld >= 0);
+  const bool lead = (!adj) & (!twin) & (same | appr) & (ld > 0);
+  const int cls = adj ? ((ld < 0) ? 3 : 2) : (twin ? 4 : (lead ? 1 : 0));
+  r.cls = close ? cls : 0;
+  r.cflag = ((v_a == -1) | (a_v == 1)) ? ooffL : ooffR;  // :146-152 which front corner of `o`
   return r;
 }
 
@@ -671,6 +690,9 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
   const long long A = st.A;
   const double dt = c.dt;
 
+#ifdef MM_STAMPS
+  unsigned long long _t_last = __builtin_amdgcn_s_memtime();
+#endif
   Veh v;
   load_veh(st, i, valid, v);
   int steps = 0, time = 0, n_merge = 0, episode = 0;
@@ -697,6 +719,7 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
   }
 
   bool env_active = n_ctrl > 0;
+  STAMP(0);  // load + setup
   for (int k = 0; k < c.nsub; k++) {
     const bool live = env_active && v.present;
     QpTrace qt = {0, __builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan(""),
@@ -802,13 +825,19 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
       if (hdv && live) v.gvx += dt;  // IDMVehicle.step: self.timer += dt (behavior.py:102-109)
     }
     if (live) clip_actions(v, LC && !hdv);
+    STAMP(1);  // act
     // predicted post-state for the nominal steering (the only one when nothing vetoes)
-    Cand cA, cB;
+    // Register relief: the lane-private values that are written once and read rarely live in LDS
+    // ("cold" slots, one column per thread): the LC-veto candidate B and the 7..15 sort keys of the
+    // classification pass.  Spilling them to scratch instead cost 25 % of the kernel time.
+    constexpr int kColdB = 7, kColdN = kColdB + (G - 1);
+    __shared__ double s_cold[SHIELDED ? kColdN : 1][256];
+    const int tid = threadIdx.x;
+    Cand cA;
     memset(&cA, 0, sizeof cA);
     const bool shield_on = SHIELDED && live && !hdv && v.hist_len >= 2;  // gate safe_controller.py:232-239
     if (live) cA = predict<KIND, SHIELDED>(v, v.act_steer, dt);
-    cB = cA;
-    double steerB = v.act_steer;
+    STAMP(2);  // predict A
     // LC veto re-steers to the CURRENT lane (decentral_layer.py:501-506,739-744); identical to the
     // nominal command unless a lane change / lane hand-over is under way or the car crashed.
     // Candidate B is only predicted when a veto actually fires (lazily, below).
@@ -816,10 +845,24 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     bool haveB = false;
     auto make_B = [&]() {
       if (SHIELDED && needB && !haveB) {
-        steerB = steering_control(v.x, v.y, v.h, v.v, v.lane);
-        cB = predict<KIND, true>(v, steerB, dt);
+        const double steerB = steering_control(v.x, v.y, v.h, v.v, v.lane);
+        const Cand cB = predict<KIND, true>(v, steerB, dt);
+        s_cold[0][tid] = cB.x; s_cold[1][tid] = cB.y; s_cold[2][tid] = cB.h; s_cold[3][tid] = cB.gvx;
+        s_cold[4][tid] = cB.cpsi; s_cold[5][tid] = steerB;
+        s_cold[6][tid] = (double)(cB.lane | cB.nl << 3 | (int)cB.offL << 6 | (int)cB.offR << 7);
         haveB = true;
       }
+    };
+    // the candidate a vehicle commits / shows to later vehicles: A, or B (from LDS) after a veto
+    auto chosen = [&](bool useB) {
+      Cand cc = cA;
+      if (SHIELDED && useB) {
+        cc.x = s_cold[0][tid]; cc.y = s_cold[1][tid]; cc.h = s_cold[2][tid]; cc.gvx = s_cold[3][tid];
+        cc.cpsi = s_cold[4][tid];
+        const int pk = (int)s_cold[6][tid];
+        cc.lane = pk & 7; cc.nl = (pk >> 3) & 7; cc.offL = ((pk >> 6) & 1) != 0; cc.offR = ((pk >> 7) & 1) != 0;
+      }
+      return cc;
     };
     double new_acc = v.act_acc;
     bool use_B = false, veto = false;
@@ -840,14 +883,12 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
         // (induction on rank: the rank-r vehicle is final after r+1 rounds / passes).
         bool irregular = false;
         for (int pass = 0; pass <= st.N; pass++) {
-          const Cand &mine = use_B ? cB : cA;
+          const Cand mine = chosen(use_B);
           // what I show to a partner: post-state if I step before it, else pre-state
           double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
           int j_ol = -1, j_oa = -1, j_oar = -1;
           Neigh nb;
           memset(&nb, 0, sizeof nb);
-          double keys[G];
-          keys[0] = INFINITY;
           bool ol_dyn = false, oa_dyn = false, oar_stepped = false;
           for_partners<G>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
@@ -872,31 +913,36 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
             const bool o_first = !i_first && p_rank < 99 && !o_hdv;
             const Rel r = relate(v.x, v.y, v.lane, nl_self, ((opk >> 8) & 1) != 0, ox, oy, oh, opk & 7, (opk >> 3) & 7,
                                  ((opk >> 6) & 1) != 0, ((opk >> 7) & 1) != 0, o_hdv);
-            keys[m] = r.key;
+            s_cold[kColdB + m - 1][tid] = r.key;
             // the on-ramp HDV "digital twin" edits the HDV's history record in place (:175-180), which
             // later egos of the sub-step read: an order dependence only the literal sweep reproduces
             if (MIXED && r.cls == 4) irregular = irregular || shield_on;
-            // running "first in sorted order" per class: smaller key, ties by creation index
-            if (r.cls == 1 && (r.key < k_ol || (r.key == k_ol && p < j_ol))) {
-              k_ol = r.key; j_ol = p; nb.ol_x = ohx; nb.ol_vx = ohvx; nb.ol_g = og; nb.ol_acc = oacc; ol_dyn = o_first;
-            }
-            if (r.cls == 2 && (r.key < k_oa || (r.key == k_oa && p < j_oa))) {
-              k_oa = r.key; j_oa = p; nb.oa_x = ohx; nb.oa_vx = ohvx; nb.oa_g = og; nb.oa_acc = oacc; oa_dyn = o_first;
-              nb.constrain_adj = r.cflag;
-            }
-            if (r.cls == 3 && (r.key < k_oar || (r.key == k_oar && p < j_oar))) {
-              k_oar = r.key; j_oar = p; nb.oar_x = ox; nb.oar_vx = ovx; oar_stepped = !i_first && p_rank < 99;
-            }
+            // running "first in sorted order" per class: smaller key, ties by creation index (selects, no branches)
+            const bool b_ol = (r.cls == 1) & ((r.key < k_ol) | ((r.key == k_ol) & (p < j_ol)));
+            const bool b_oa = (r.cls == 2) & ((r.key < k_oa) | ((r.key == k_oa) & (p < j_oa)));
+            const bool b_oar = (r.cls == 3) & ((r.key < k_oar) | ((r.key == k_oar) & (p < j_oar)));
+            k_ol = b_ol ? r.key : k_ol; j_ol = b_ol ? p : j_ol;
+            nb.ol_x = b_ol ? ohx : nb.ol_x; nb.ol_vx = b_ol ? ohvx : nb.ol_vx;
+            nb.ol_g = b_ol ? og : nb.ol_g; nb.ol_acc = b_ol ? oacc : nb.ol_acc; ol_dyn = b_ol ? o_first : ol_dyn;
+            k_oa = b_oa ? r.key : k_oa; j_oa = b_oa ? p : j_oa;
+            nb.oa_x = b_oa ? ohx : nb.oa_x; nb.oa_vx = b_oa ? ohvx : nb.oa_vx;
+            nb.oa_g = b_oa ? og : nb.oa_g; nb.oa_acc = b_oa ? oacc : nb.oa_acc; oa_dyn = b_oa ? o_first : oa_dyn;
+            nb.constrain_adj = b_oa ? r.cflag : nb.constrain_adj;
+            k_oar = b_oar ? r.key : k_oar; j_oar = b_oar ? p : j_oar;
+            nb.oar_x = b_oar ? ox : nb.oar_x; nb.oar_vx = b_oar ? ovx : nb.oar_vx;
+            oar_stepped = b_oar ? ((!i_first) & (p_rank < 99)) : oar_stepped;
           });
+          STAMP(3);  // S1 partner classification
           // count = 5 of close_vehicles_to: a slot exists only if its vehicle is among the 5 nearest
           {
             int pos_ol = 0, pos_oa = 0, pos_oar = 0;
 #pragma unroll
             for (int m = 1; m < G; m++) {
               const int p = a ^ m;
-              pos_ol += (keys[m] < k_ol || (keys[m] == k_ol && p < j_ol)) ? 1 : 0;
-              pos_oa += (keys[m] < k_oa || (keys[m] == k_oa && p < j_oa)) ? 1 : 0;
-              pos_oar += (keys[m] < k_oar || (keys[m] == k_oar && p < j_oar)) ? 1 : 0;
+              const double km = s_cold[kColdB + m - 1][tid];
+              pos_ol += (km < k_ol || (km == k_ol && p < j_ol)) ? 1 : 0;
+              pos_oa += (km < k_oa || (km == k_oa && p < j_oa)) ? 1 : 0;
+              pos_oar += (km < k_oar || (km == k_oar && p < j_oar)) ? 1 : 0;
             }
             nb.has_ol = j_ol >= 0 && pos_ol < 5;
             nb.has_oa = j_oa >= 0 && pos_oa < 5;
@@ -930,8 +976,10 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
             acc_cur = acc_next;
             if (!MASS || !__any(changed)) break;
           }
+          STAMP(4);  // selection + fixed-point rounds
           const bool want_B = shield_on && so.veto && needB;
           if (want_B) make_B();
+          STAMP(5);  // lazy candidate B
           const bool flip = want_B != use_B;
           use_B = want_B;
           if (!__any(flip)) break;
@@ -1024,7 +1072,7 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
           if (has && a == ai && shield_on) {
             new_acc = s1.acc; veto = s1.veto; new_flags = s1.flags; qt = s1.qt;
             use_B = veto && needB;
-            const Cand &cc = use_B ? cB : cA;
+            const Cand cc = chosen(use_B);
             double nv = v.v + new_acc * dt;
             nv = nv > 0 ? nv : 0;
             // publish my post-step view (Vehicle.step committed) for the later stages
@@ -1036,9 +1084,16 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
         if (MIXED && hdv && twin_shift != 0 && w_stepped) v.h1x = whx;
       }
     }
+    STAMP(6);  // serial fallback (if taken) + sweep exit
+    if (SHIELDED && out.trace && live) {  // QP internals go out now so they need not stay in registers
+      double *t = out.trace + (long long)k * MM_T_COUNT * A + i;
+      t[MM_T_QP_ROWS * A] = qt.rows; t[MM_T_QP_A * A] = qt.a;
+      t[MM_T_QP_H0 * A] = qt.h0; t[MM_T_QP_H1 * A] = qt.h1; t[MM_T_QP_H2 * A] = qt.h2;
+      t[MM_T_QP_H3 * A] = qt.h3; t[MM_T_QP_D * A] = qt.d; t[MM_T_LC_MARGIN * A] = qt.margin;
+    }
     // ---------------- commit Vehicle.step / MDPLCVehicle.step for every vehicle -------------------
     if (live) {
-      const Cand &cc = use_B ? cB : cA;
+      const Cand cc = chosen(use_B);
       const double acc = (SHIELDED && shield_on) ? new_acc : v.act_acc;
       double nv = v.v + acc * dt;
       nv = nv > 0 ? nv : 0;  // max(0, speed)
@@ -1049,7 +1104,8 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
       v.x = cc.x; v.y = cc.y; v.h = cc.h; v.v = nv; v.lane = cc.lane;
       if (LC) {
         if (!hdv) {
-          v.safe_steer = (SHIELDED && shield_on && veto) ? steerB : v.act_steer;
+          // a veto re-steers to the current lane; identical to the nominal command unless B was needed
+          v.safe_steer = (SHIELDED && shield_on && veto && haveB) ? s_cold[5][tid] : v.act_steer;
           v.safe_acc = acc; v.gvx = cc.gvx;
         }
         v.h2x = v.h1x; v.h2vx = v.h1vx;  // log_step :187-201 (IDMVehicleHist: behavior.py:505-521)
@@ -1060,6 +1116,7 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
       if (SHIELDED) { offL = cc.offL; offR = cc.offR; nl_self = cc.nl; }
     }
 
+    STAMP(7);  // commit
     // ---------------- collisions (road.py:288-292, kinematics.py:175-209) ----------------------
     unsigned hits = 0;
     for_partners<G>([&](auto mc) {
@@ -1067,13 +1124,13 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
       double px = dppx_d<m>(v.x), py = dppx_d<m>(v.y), ph = dppx_d<m>(v.h);
       bool pp = dppx_i<m>((int)live) != 0;
       double dx = px - v.x, dy = py - v.y;
-      if (live && pp && !(sqrt(dx * dx + dy * dy) > kVehLength))
+      if (live && pp && !((dx * dx + dy * dy) > kU5))  // norm > LENGTH pre-check, sqrt-free
         if (rects_intersect(v.x, v.y, v.h, px, py, kVehLength, kVehWidth, ph)) hits |= 1u << (a ^ m);
     });
     bool obst_hit = false;
     if (live) {
       double dx = kObstX - v.x, dy = kObstY - v.y;
-      if (!(sqrt(dx * dx + dy * dy) > kVehLength)) obst_hit = rects_intersect(v.x, v.y, v.h, kObstX, kObstY, 2.0, 2.0, 0.0);
+      if (!((dx * dx + dy * dy) > kU5)) obst_hit = rects_intersect(v.x, v.y, v.h, kObstX, kObstY, 2.0, 2.0, 0.0);
     }
     if (__any(hits != 0 || obst_hit)) {
       // order-dependent part: creation-order double loop, min-|speed| hand-down (kinematics.py:187-196)
@@ -1096,6 +1153,7 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
         }
       }
     }
+    STAMP(8);  // collisions
     if (env_active) time += 1;
     if (out.trace && live) {
       double *t = out.trace + (long long)k * MM_T_COUNT * A + i;
@@ -1104,15 +1162,15 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
       t[MM_T_SAFE_STEER * A] = (LC && !hdv) ? v.safe_steer : v.act_steer;
       t[MM_T_SAFE_ACC * A] = (LC && !hdv) ? v.safe_acc : v.act_acc;
       t[MM_T_LANE * A] = v.lane; t[MM_T_TARGET_LANE * A] = v.tlane; t[MM_T_CRASHED * A] = v.crashed;
-      t[MM_T_FLAGS * A] = v.flags; t[MM_T_QP_ROWS * A] = qt.rows; t[MM_T_QP_A * A] = qt.a;
-      t[MM_T_QP_H0 * A] = qt.h0; t[MM_T_QP_H1 * A] = qt.h1; t[MM_T_QP_H2 * A] = qt.h2;
-      t[MM_T_QP_H3 * A] = qt.h3; t[MM_T_QP_D * A] = qt.d; t[MM_T_LC_MARGIN * A] = qt.margin;
+      t[MM_T_FLAGS * A] = v.flags;
+      if (!SHIELDED) t[MM_T_QP_ROWS * A] = 0;  // the other QP planes keep the NaN fill
     }
     // _is_terminal (merge_env_v1.py:168-172) breaks the sub-step loop (abstract.py:530)
     const bool term = group_ballot<G>(ctrl && (v.crashed || v.x < 0), gb) != 0 || steps >= c.T;
     if (term) env_active = false;
   }
 
+  STAMP(9);  // trace + terminal
   // ---------------- rewards / info (merge_env_v1.py:59-166, abstract.py:469-498) -----------------
   const bool env_ok = n_ctrl > 0;
   const unsigned crashed_bits = group_ballot<G>(ctrl && v.crashed, gb);
@@ -1253,6 +1311,7 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     if (threadIdx.x < 7) atomicAdd(&metrics[threadIdx.x], s_m[threadIdx.x]);
     if (threadIdx.x == 7) atomic_min_d(&metrics[7], s_m[7]);
   }
+  STAMP(10);  // rewards + outputs + metrics
   // ---------------- optional re-spawn (marl/mappo.py:133-135 `if done: env.reset()`) --------------
   if (c.auto_reset && done) {
     const uint64_t seed = st.seeds[e];
@@ -1269,7 +1328,9 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     st.I[MM_E_STEPS * st.E + e] = steps; st.I[MM_E_TIME * st.E + e] = time;
     st.I[MM_E_N_MERGE * st.E + e] = n_merge; st.I[MM_E_EPISODE * st.E + e] = episode;
   }
+  STAMP(11);  // re-spawn + state store
   observe<G, KIND>(c, v, a, gb, i, valid, out.obs, out.action_mask);
+  STAMP(12);  // observation
 }
 
 // reset / init / observe --------------------------------------------------------------------------
@@ -1709,3 +1770,14 @@ extern "C" int32_t mm_math_eval(int32_t fn, int32_t n, const double *x, const do
   hipLaunchKernelGGL(math_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, fn, n, x, x2, y);
   return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_DEVICE;
 }
+
+#ifdef MM_STAMPS
+extern "C" int32_t mm_debug_read_stamps(unsigned long long *out16, int32_t reset) {
+  hipError_t rc = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+  if (rc == hipSuccess && reset) {
+    unsigned long long z[16] = {0};
+    rc = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
+  }
+  return rc == hipSuccess ? MM_OK : MM_ERR_DEVICE;
+}
+#endif
