@@ -339,9 +339,9 @@ MM_DEV int spawn_vehicle(Veh &v, int a, int n_cav, int n_hdv, uint64_t seed, uin
 // ------------------------------------------------------------------------------------------------
 // observation (envs/common/observation.py:181-273) + action mask (abstract.py:219-240)
 // ------------------------------------------------------------------------------------------------
-template <int G, int KIND>
+template <int G, int KIND, bool LEND = false>
 MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, bool valid, void *obs,
-                    uint8_t *avail) {
+                    uint8_t *avail, float *stage = nullptr) {
   constexpr int F = (KIND == MM_ENV_V1) ? 6 : 5;
   const bool ctrl = v.present && v.kind != 2;  // only controlled vehicles observe / have an action mask
   double sps, cps;
@@ -410,8 +410,13 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
     // (a lane's 5F floats are 100/120 B apart from its neighbour's: direct stores would touch 64
     // different cache lines per instruction and tripled the measured WRITE_SIZE).
     constexpr int S = 5 * F;
-    __shared__ float s_obs[4][64 * S];
-    float *sw = s_obs[threadIdx.x >> 6];
+    float *sw;
+    if constexpr (LEND) {
+      sw = stage + (threadIdx.x >> 6) * (64 * S);  // the caller lends LDS it no longer needs
+    } else {
+      __shared__ float s_obs[4][64 * S];
+      sw = s_obs[threadIdx.x >> 6];
+    }
     const int lane = lane_id();
     const int slot = (lane / G) * c.N + a;  // valid lanes of a wave are contiguous in agent index
     if (valid) emit([&](int k, double val) { sw[slot * S + k] = (float)val; });
@@ -675,8 +680,14 @@ MM_DEV Rel relate(double ex, double ey, int elane, int enl, bool other, double o
 #ifndef MM_MIN_WAVES
 #define MM_MIN_WAVES 2  // 2 waves/SIMD: measured 0.62 ms vs 0.98 (1) / 0.92 (3, spills) at 65536x8 MASS
 #endif
+// The shielded 16-lane groups carry twice the partner state: at 2 waves/SIMD they spill ~1 KB/lane
+// to scratch; with the whole 512-register file (1 wave/SIMD) they run 1.6x faster (1.22 vs 1.93 ms
+// at 32768 x 12 MASS) -- and it is the configuration the toolchain compiles correctly (DESIGN.md
+// "toolchain note").
+template <int G, int SHIELD>
+constexpr int step_min_waves() { return (G == 16 && SHIELD != MM_SHIELD_NONE) ? 1 : MM_MIN_WAVES; }
 template <int G, int KIND, int SHIELD, bool MIXED>
-__global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
+__global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
                                                    MMStepOut out, double *metrics) {
   constexpr bool LC = (KIND == MM_ENV_V1);
   constexpr bool SHIELDED = LC && (SHIELD != MM_SHIELD_NONE);
@@ -718,6 +729,20 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     nl_self = next_lane(v.lane, v.x, v.y);
   }
 
+  // Register relief: lane-private values that are written once and read rarely live in LDS ("cold"
+  // slots, one column per thread) instead of being spilled to scratch by the compiler (measured: each
+  // 100 B/lane of scratch costs ~8 % of the kernel): the LC-veto candidate B, the history records,
+  // the previous safe action, the target speed, and the 7..15 sort keys of the classification pass.
+  enum { C_B = 0, C_H1X = 7, C_H1VX, C_H2X, C_H2VX, C_SSTEER, C_SACC, C_TSPEED, C_A = 14, kColdB = 21 };
+  constexpr int kColdN = kColdB + (G - 1);
+  static_assert(kColdN * 2048 >= 4 * 64 * 30 * 4, "the obs staging must fit in the cold slots");
+  __shared__ double s_cold[kColdN][256];
+  const int tid = threadIdx.x;
+  if (LC) {
+    s_cold[C_H1X][tid] = v.h1x; s_cold[C_H1VX][tid] = v.h1vx; s_cold[C_H2X][tid] = v.h2x; s_cold[C_H2VX][tid] = v.h2vx;
+    s_cold[C_SSTEER][tid] = v.safe_steer; s_cold[C_SACC][tid] = v.safe_acc;
+  }
+  s_cold[C_TSPEED][tid] = v.tspeed;
   bool env_active = n_ctrl > 0;
   STAMP(0);  // load + setup
   for (int k = 0; k < c.nsub; k++) {
@@ -734,11 +759,13 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
         rank += (pp && (px > v.x || (px == v.x && (a ^ m) < a))) ? 1 : 0;
       });
     }
+    v.tspeed = s_cold[C_TSPEED][tid];
     if (live && !hdv) {
       if (time % c.nsub == 0) hl_act<KIND>(v, action);  // action_type.act abstract.py:516-519
     }
     const int tl_pre = v.tlane;  // what an HDV acting before this vehicle still sees
     if (live && !hdv) controlled_act(v, -1);  // road.act road.py:269-278
+    s_cold[C_TSPEED][tid] = v.tspeed;
     if constexpr (MIXED) {
       // ---------------- IDMVehicle.act for the HDVs (behavior.py:74-100) -------------------------
       // Positions do not move during Road.act, so each HDV scans its neighbours in parallel.  The one
@@ -827,16 +854,16 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     if (live) clip_actions(v, LC && !hdv);
     STAMP(1);  // act
     // predicted post-state for the nominal steering (the only one when nothing vetoes)
-    // Register relief: the lane-private values that are written once and read rarely live in LDS
-    // ("cold" slots, one column per thread): the LC-veto candidate B and the 7..15 sort keys of the
-    // classification pass.  Spilling them to scratch instead cost 25 % of the kernel time.
-    constexpr int kColdB = 7, kColdN = kColdB + (G - 1);
-    __shared__ double s_cold[SHIELDED ? kColdN : 1][256];
-    const int tid = threadIdx.x;
     Cand cA;
     memset(&cA, 0, sizeof cA);
     const bool shield_on = SHIELDED && live && !hdv && v.hist_len >= 2;  // gate safe_controller.py:232-239
     if (live) cA = predict<KIND, SHIELDED>(v, v.act_steer, dt);
+    auto park = [&](int base, const Cand &cc, double steer) {  // a candidate's LDS image
+      s_cold[base + 0][tid] = cc.x; s_cold[base + 1][tid] = cc.y; s_cold[base + 2][tid] = cc.h;
+      s_cold[base + 3][tid] = cc.gvx; s_cold[base + 4][tid] = cc.cpsi; s_cold[base + 5][tid] = steer;
+      s_cold[base + 6][tid] = (double)(cc.lane | cc.nl << 3 | (int)cc.offL << 6 | (int)cc.offR << 7);
+    };
+    if (SHIELDED) park(C_A, cA, v.act_steer);
     STAMP(2);  // predict A
     // LC veto re-steers to the CURRENT lane (decentral_layer.py:501-506,739-744); identical to the
     // nominal command unless a lane change / lane hand-over is under way or the car crashed.
@@ -846,22 +873,28 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     auto make_B = [&]() {
       if (SHIELDED && needB && !haveB) {
         const double steerB = steering_control(v.x, v.y, v.h, v.v, v.lane);
-        const Cand cB = predict<KIND, true>(v, steerB, dt);
-        s_cold[0][tid] = cB.x; s_cold[1][tid] = cB.y; s_cold[2][tid] = cB.h; s_cold[3][tid] = cB.gvx;
-        s_cold[4][tid] = cB.cpsi; s_cold[5][tid] = steerB;
-        s_cold[6][tid] = (double)(cB.lane | cB.nl << 3 | (int)cB.offL << 6 | (int)cB.offR << 7);
+        park(C_B, predict<KIND, true>(v, steerB, dt), steerB);
         haveB = true;
       }
     };
     // the candidate a vehicle commits / shows to later vehicles: A, or B (from LDS) after a veto
     auto chosen = [&](bool useB) {
-      Cand cc = cA;
-      if (SHIELDED && useB) {
-        cc.x = s_cold[0][tid]; cc.y = s_cold[1][tid]; cc.h = s_cold[2][tid]; cc.gvx = s_cold[3][tid];
-        cc.cpsi = s_cold[4][tid];
-        const int pk = (int)s_cold[6][tid];
-        cc.lane = pk & 7; cc.nl = (pk >> 3) & 7; cc.offL = ((pk >> 6) & 1) != 0; cc.offR = ((pk >> 7) & 1) != 0;
-      }
+      if (!SHIELDED) return cA;
+#ifdef MM_T_REGA
+      if (!useB) return cA;
+#endif
+      const int base = useB ? C_B : C_A;  // both candidates sit in LDS; A's registers are free meanwhile
+      Cand cc;
+      cc.x = s_cold[base + 0][tid]; cc.y = s_cold[base + 1][tid]; cc.h = s_cold[base + 2][tid];
+      cc.gvx = s_cold[base + 3][tid]; cc.cpsi = s_cold[base + 4][tid];
+      const int pk = (int)s_cold[base + 6][tid];
+      cc.lane = pk & 7; cc.nl = (pk >> 3) & 7; cc.offL = ((pk >> 6) & 1) != 0; cc.offR = ((pk >> 7) & 1) != 0;
+#ifdef MM_T_REGPK
+      if (!useB) { cc.lane = cA.lane; cc.nl = cA.nl; cc.offL = cA.offL; cc.offR = cA.offR; }
+#endif
+#ifdef MM_T_REGPOSE
+      if (!useB) { cc.x = cA.x; cc.y = cA.y; cc.h = cA.h; cc.gvx = cA.gvx; cc.cpsi = cA.cpsi; }
+#endif
       return cc;
     };
     double new_acc = v.act_acc;
@@ -899,10 +932,10 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
             const double sx_ = i_first ? mine.x : v.x, sy_ = i_first ? mine.y : v.y, sh_ = i_first ? mine.h : v.h;
             const int spk = i_first ? (mine.lane | mine.nl << 3 | (int)mine.offL << 6 | (int)mine.offR << 7)
                                     : (v.lane | nl_self << 3 | (int)offL << 6 | (int)offR << 7);
-            const double shx = i_first ? v.h1x : v.h2x, shvx = i_first ? v.h1vx : v.h2vx;  // my state_hist[-2] as seen then
+            const double shx = s_cold[i_first ? C_H1X : C_H2X][tid], shvx = s_cold[i_first ? C_H1VX : C_H2VX][tid];  // my state_hist[-2] as seen then
             // an HDV has no safe_action / fg_params: followers assume (0, -12.5) and g.vx = 1 (:129-135,:205-211)
             const double sg = hdv ? 1.0 : (i_first ? mine.gvx : v.gvx);
-            const double sacc = hdv ? kCbfAccLo : v.safe_acc;  // my previous decision (read only if I have not stepped)
+            const double sacc = hdv ? kCbfAccLo : s_cold[C_SACC][tid];  // my previous decision (read only if I have not stepped)
             const double svx = v.v * cpsi;    // my current vx (rear-adjacent slot reads to_dict())
             const double ox = dppx_d<m>(sx_), oy = dppx_d<m>(sy_), oh = dppx_d<m>(sh_);
             const int opk = dppx_i<m>(spk | (int)live << 8 | (int)hdv << 9);
@@ -977,6 +1010,9 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
             if (!MASS || !__any(changed)) break;
           }
           STAMP(4);  // selection + fixed-point rounds
+#ifdef MM_DBGPRINT
+          if (e == 0 && k == 2) printf("PAR a=%d pass=%d rank=%d j_ol=%d j_oa=%d j_oar=%d has=%d%d%d ol_dyn=%d olx=%.9f olvx=%.9f olacc=%.9f olg=%.9f acc=%.9f h0=%.9f son=%d irr=%d\n", a, pass, rank, j_ol, j_oa, j_oar, (int)nb.has_ol, (int)nb.has_oa, (int)nb.has_oar, (int)ol_dyn, nb.ol_x, nb.ol_vx, nb.ol_acc, nb.ol_g, so.acc, so.qt.h0, (int)shield_on, (int)irregular);
+#endif
           const bool want_B = shield_on && so.veto && needB;
           if (want_B) make_B();
           STAMP(5);  // lazy candidate B
@@ -994,8 +1030,8 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
         make_B();
         use_B = false; veto = false; new_acc = v.act_acc; new_flags = v.flags;
         // working copy of what the others see of me; committed stage by stage
-        double wx = v.x, wy = v.y, wh = v.h, wg = hdv ? 1.0 : v.gvx, wacc = hdv ? kCbfAccLo : v.safe_acc, wvx = v.v * cpsi;
-        double whx = v.h2x, whvx = v.h2vx;
+        double wx = v.x, wy = v.y, wh = v.h, wg = hdv ? 1.0 : v.gvx, wacc = hdv ? kCbfAccLo : s_cold[C_SACC][tid], wvx = v.v * cpsi;
+        double whx = s_cold[C_H2X][tid], whvx = s_cold[C_H2VX][tid];
         int wlane = v.lane, wnl = nl_self;
         bool woffL = offL, woffR = offR;
         if (MIXED && hdv && live) {
@@ -1008,8 +1044,9 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
           if (MIXED && live && hdv && rank == r && !w_stepped) {
             // an HDV at its turn just steps (no shield): later egos see its post-step pose, and its
             // state_hist[-2] is then the record it held as [-1] before
-            wx = cA.x; wy = cA.y; wh = cA.h; wlane = cA.lane; wnl = cA.nl; woffL = cA.offL; woffR = cA.offR;
-            whx = v.h1x; whvx = v.h1vx; w_stepped = true; twin_shift = 0;
+            const Cand ca = chosen(false);
+            wx = ca.x; wy = ca.y; wh = ca.h; wlane = ca.lane; wnl = ca.nl; woffL = ca.offL; woffR = ca.offR;
+            whx = s_cold[C_H1X][tid]; whvx = s_cold[C_H1VX][tid]; w_stepped = true; twin_shift = 0;
           }
           const unsigned sel = group_ballot<G>(shield_on && rank == r, gb);
           const bool has = sel != 0;
@@ -1072,16 +1109,19 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
           if (has && a == ai && shield_on) {
             new_acc = s1.acc; veto = s1.veto; new_flags = s1.flags; qt = s1.qt;
             use_B = veto && needB;
+#ifdef MM_DBGPRINT
+            if (e == 0 && k == 2) printf("SER a=%d rank=%d has=%d%d%d olx=%.9f olvx=%.9f olacc=%.9f olg=%.9f acc=%.9f h0=%.9f\n", a, rank, (int)nb.has_ol, (int)nb.has_oa, (int)nb.has_oar, nb.ol_x, nb.ol_vx, nb.ol_acc, nb.ol_g, s1.acc, s1.qt.h0);
+#endif
             const Cand cc = chosen(use_B);
             double nv = v.v + new_acc * dt;
             nv = nv > 0 ? nv : 0;
             // publish my post-step view (Vehicle.step committed) for the later stages
             wx = cc.x; wy = cc.y; wh = cc.h; wg = cc.gvx; wacc = new_acc; wvx = nv * cc.cpsi;
-            whx = v.h1x; whvx = v.h1vx; wlane = cc.lane; wnl = cc.nl; woffL = cc.offL; woffR = cc.offR;
+            whx = s_cold[C_H1X][tid]; whvx = s_cold[C_H1VX][tid]; wlane = cc.lane; wnl = cc.nl; woffL = cc.offL; woffR = cc.offR;
           }
         }
         // the in-place history edits persist in the record that becomes state_hist[-2] (stepped HDV)
-        if (MIXED && hdv && twin_shift != 0 && w_stepped) v.h1x = whx;
+        if (MIXED && hdv && twin_shift != 0 && w_stepped) s_cold[C_H1X][tid] = whx;
       }
     }
     STAMP(6);  // serial fallback (if taken) + sweep exit
@@ -1105,11 +1145,11 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
       if (LC) {
         if (!hdv) {
           // a veto re-steers to the current lane; identical to the nominal command unless B was needed
-          v.safe_steer = (SHIELDED && shield_on && veto && haveB) ? s_cold[5][tid] : v.act_steer;
-          v.safe_acc = acc; v.gvx = cc.gvx;
+          s_cold[C_SSTEER][tid] = (SHIELDED && shield_on && veto && haveB) ? s_cold[C_B + 5][tid] : v.act_steer;
+          s_cold[C_SACC][tid] = acc; v.gvx = cc.gvx;
         }
-        v.h2x = v.h1x; v.h2vx = v.h1vx;  // log_step :187-201 (IDMVehicleHist: behavior.py:505-521)
-        v.h1x = v.x; v.h1vx = v.v * cc.cpsi;
+        s_cold[C_H2X][tid] = s_cold[C_H1X][tid]; s_cold[C_H2VX][tid] = s_cold[C_H1VX][tid];  // log_step :187-201 (IDMVehicleHist: behavior.py:505-521)
+        s_cold[C_H1X][tid] = v.x; s_cold[C_H1VX][tid] = v.v * cc.cpsi;
         if (v.hist_len < 2) v.hist_len++;
       }
       if (SHIELDED || MIXED) cpsi = cc.cpsi;
@@ -1159,8 +1199,8 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
       double *t = out.trace + (long long)k * MM_T_COUNT * A + i;
       t[MM_T_X * A] = v.x; t[MM_T_Y * A] = v.y; t[MM_T_HEADING * A] = v.h; t[MM_T_SPEED * A] = v.v;
       t[MM_T_ACT_STEER * A] = v.act_steer; t[MM_T_ACT_ACC * A] = v.act_acc;
-      t[MM_T_SAFE_STEER * A] = (LC && !hdv) ? v.safe_steer : v.act_steer;
-      t[MM_T_SAFE_ACC * A] = (LC && !hdv) ? v.safe_acc : v.act_acc;
+      t[MM_T_SAFE_STEER * A] = (LC && !hdv) ? s_cold[C_SSTEER][tid] : v.act_steer;
+      t[MM_T_SAFE_ACC * A] = (LC && !hdv) ? s_cold[C_SACC][tid] : v.act_acc;
       t[MM_T_LANE * A] = v.lane; t[MM_T_TARGET_LANE * A] = v.tlane; t[MM_T_CRASHED * A] = v.crashed;
       t[MM_T_FLAGS * A] = v.flags;
       if (!SHIELDED) t[MM_T_QP_ROWS * A] = 0;  // the other QP planes keep the NaN fill
@@ -1319,17 +1359,33 @@ __global__ __launch_bounds__(256, MM_MIN_WAVES) void step_kernel(DevCfg c, DevSt
     memset(&nv, 0, sizeof nv);
     int nm = 0;
     if (valid && v.present) nm = spawn_vehicle(nv, a, n_ctrl, n_veh - n_ctrl, seed, (uint32_t)episode);
-    if (valid && v.present) v = nv;
+    if (valid && v.present) {
+      v = nv;
+      s_cold[C_H1X][tid] = v.h1x; s_cold[C_H1VX][tid] = v.h1vx; s_cold[C_H2X][tid] = v.h2x; s_cold[C_H2VX][tid] = v.h2vx;
+      s_cold[C_SSTEER][tid] = v.safe_steer; s_cold[C_SACC][tid] = v.safe_acc; s_cold[C_TSPEED][tid] = v.tspeed;
+    }
     n_merge = shfl_i(nm, gb);
     steps = 0; time = 0; episode += 1;
   }
-  if (valid && v.present) store_veh(st, i, v);
+  if (valid && v.present) {
+    if (LC) {
+      v.h1x = s_cold[C_H1X][tid]; v.h1vx = s_cold[C_H1VX][tid]; v.h2x = s_cold[C_H2X][tid]; v.h2vx = s_cold[C_H2VX][tid];
+      if (!hdv) { v.safe_steer = s_cold[C_SSTEER][tid]; v.safe_acc = s_cold[C_SACC][tid]; }
+    }
+    v.tspeed = s_cold[C_TSPEED][tid];
+    store_veh(st, i, v);
+  }
   if (e < st.E && a == 0) {
     st.I[MM_E_STEPS * st.E + e] = steps; st.I[MM_E_TIME * st.E + e] = time;
     st.I[MM_E_N_MERGE * st.E + e] = n_merge; st.I[MM_E_EPISODE * st.E + e] = episode;
   }
   STAMP(11);  // re-spawn + state store
+  __syncthreads();  // every wave is done with its cold slots: the obs staging below reuses that LDS
+#ifdef MM_T_NOLEND
   observe<G, KIND>(c, v, a, gb, i, valid, out.obs, out.action_mask);
+#else
+  observe<G, KIND, true>(c, v, a, gb, i, valid, out.obs, out.action_mask, (float *)&s_cold[0][0]);
+#endif
   STAMP(12);  // observation
 }
 
@@ -1628,8 +1684,8 @@ static void launch_reset_g(MMHandle h, int mode, const uint8_t *mask, const uint
 static int launch_reset(MMHandle h, int mode, const uint8_t *mask, const uint64_t *seeds, void *obs,
                         uint8_t *avail, MMStream stream) {
   hipStream_t s = (hipStream_t)stream;
-#ifdef MM_ONLY_G8
-  launch_reset_g<8>(h, mode, mask, seeds, obs, avail, s);
+#ifdef MM_ONLY_G
+  launch_reset_g<MM_ONLY_G>(h, mode, mask, seeds, obs, avail, s);
 #else
   switch (group_size(h->N)) {
     case 2: launch_reset_g<2>(h, mode, mask, seeds, obs, avail, s); break;
@@ -1665,6 +1721,10 @@ static void launch_step_t(MMHandle h, const int32_t *actions, const MMStepOut *o
 }
 template <int G, bool MIXED>
 static void launch_step_m(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+#ifdef MM_ONLY_SHIELD  // tuning builds: v1 with one shield
+  launch_step_t<G, MM_ENV_V1, MM_ONLY_SHIELD, MIXED>(h, actions, out, s);
+  return;
+#endif
   if (h->cfg.env_kind == MM_ENV_V0) { launch_step_t<G, MM_ENV_V0, MM_SHIELD_NONE, MIXED>(h, actions, out, s); return; }
   switch (h->cfg.shield) {
     case MM_SHIELD_HSS: launch_step_t<G, MM_ENV_V1, MM_SHIELD_HSS, MIXED>(h, actions, out, s); break;
@@ -1676,8 +1736,12 @@ static void launch_step_m(MMHandle h, const int32_t *actions, const MMStepOut *o
 // keep the leaner instantiation
 template <int G>
 static void launch_step_g(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+#ifdef MM_ONLY_MIXED  // tuning builds
+  launch_step_m<G, MM_ONLY_MIXED>(h, actions, out, s);
+#else
   if (h->cfg.n_hdv > 0) launch_step_m<G, true>(h, actions, out, s);
   else launch_step_m<G, false>(h, actions, out, s);
+#endif
 }
 
 extern "C" int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStream stream) {
@@ -1688,8 +1752,8 @@ extern "C" int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *
     hipError_t rc = hipMemsetAsync(out->trace, 0xFF, (size_t)3 * MM_T_COUNT * h->E * h->N * sizeof(double), s);
     if (rc != hipSuccess) return hip_fail(h, rc, "trace memset");
   }
-#ifdef MM_ONLY_G8  // tuning builds: one instantiation, seconds to compile
-  launch_step_g<8>(h, actions, out, s);
+#ifdef MM_ONLY_G  // tuning builds: one group size, seconds to compile
+  launch_step_g<MM_ONLY_G>(h, actions, out, s);
 #else
   switch (group_size(h->N)) {
     case 2: launch_step_g<2>(h, actions, out, s); break;
@@ -1720,8 +1784,8 @@ extern "C" int32_t mm_shield_actions(MMHandle h, const double *act_steer, const 
                                      double *safe_acc, uint8_t *status, double *margin, MMStream stream) {
   if (!h || !act_steer || !act_acc || !safe_steer || !safe_acc) return MM_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
-#ifdef MM_ONLY_G8
-  launch_shield_g<8>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, s);
+#ifdef MM_ONLY_G
+  launch_shield_g<MM_ONLY_G>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, s);
 #else
   switch (group_size(h->N)) {
     case 2: launch_shield_g<2>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, s); break;

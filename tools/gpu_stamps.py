@@ -1,4 +1,4 @@
-"""Diagnostic: per-phase cycle shares of step_kernel (build with -DMM_STAMPS -DMM_ONLY_G8)."""
+"""Diagnostic: per-phase cycle shares of step_kernel (build with -DMM_STAMPS -DMM_ONLY_G=8)."""
 import ctypes, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
