@@ -126,6 +126,28 @@ def main():
         agent_steps = float(E) * N * args.steps * world
         b_alg = algorithmic_bytes_per_agent_step(args.env_id, N)
         achieved = E * N * b_alg / (kern_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC passes (profiles/traffic.json, written from
+        # tools/profile.sh on the same workload); null for any other workload
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")))
+            w = tj["workload"]
+            if (w["envs_per_gpu"], w["agents"], w["shield"], w["env_id"]) == (E, N, args.shield, args.env_id):
+                traffic = tj["bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
+        # secondary reading (the kernel is VALU-issue bound): instructions from the committed
+        # SQ_INSTS_VALU pass x 4 issue cycles per wave64 instruction, against 1024 SIMDs at the 2.4 GHz peak clock
+        valu = None
+        try:
+            sj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "step_kernel_summary.json")))
+            if traffic is not None:
+                n_valu = sj["pmc_per_launch"]["SQ_INSTS_VALU"] / sj["pmc_per_launch"]["SQ_WAVES"] * (E * 8 // 64 if N <= 8 else E * 16 // 64)
+                ach = n_valu * 4 / (kern_ms * 1e-3) / 1e12
+                valu = {"bound": "valu-issue", "achieved": ach, "peak": 1024 * 2.4e9 / 1e12, "unit": "T SIMD-cycles/s",
+                        "frac": ach / (1024 * 2.4e9 / 1e12), "valu_insts_per_wave": sj["pmc_per_launch"]["SQ_INSTS_VALU"] / sj["pmc_per_launch"]["SQ_WAVES"]}
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            pass
         line = {
             "metric": "agent-steps/sec (whole node), MASS CBF shield on, 65536 envs x 8 CAVs" if args.shield == "mass"
                       else "agent-steps/sec (whole node), shield=%s" % args.shield,
@@ -138,12 +160,16 @@ def main():
                        "envs_per_gpu": E, "agents": N, "obs_dtype": "f64" if args.obs_f64 else "f32",
                        "parallelism": "env-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/)",
+                         "alg_bytes_per_launch": E * N * b_alg,
                          "kernel": "step_kernel", "kernel_ms": kern_ms, "alg_bytes_per_agent_step": b_alg},
             "rollout_metrics": {"mean_reward": m[0] / max(m[4], 1), "crashed_episodes": m[1],
                                 "mean_speed": m[2] / max(m[4], 1), "env_steps": m[4],
                                 "mean_merge_percent": m[5] / max(m[6], 1), "episodes": m[6], "min_headway": m[7]},
         }
+        if valu is not None:
+            line["roofline_secondary"] = valu
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.env_id, cfg, kw)
         print(json.dumps(line))

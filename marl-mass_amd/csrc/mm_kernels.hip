@@ -1021,6 +1021,10 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
           if (!__any(flip)) break;
         }
         serial = __any(irregular);
+#ifdef MM_STAMPS
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&g_stamps[13], 1ull); if (serial) atomicAdd(&g_stamps[14], 1ull); }
+        if (irregular) atomicAdd(&g_stamps[15], 1ull);
+#endif
         if (!serial && shield_on) {
           new_acc = so.acc; veto = so.veto; new_flags = so.flags; qt = so.qt;
         }

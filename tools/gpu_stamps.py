@@ -25,3 +25,4 @@ waves = E * 8 / 64
 for k, nme in enumerate(names):
     print("%-20s %6.2f %%   %8.0f cycles/wave/step" % (nme, 100.0 * buf[k] / tot, buf[k] / waves / K))
 print("total %.0f cycles/wave/step" % (tot / waves / K))
+print("shielded wave-sub-steps %d, of which serial fallback %d (%.2f %%); irregular lanes %d" % (buf[13], buf[14], 100.0 * buf[14] / max(buf[13], 1), buf[15]))
