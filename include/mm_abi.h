@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 3
+#define MM_ABI_VERSION 4
 #define MM_MAX_AGENTS 16 /* vehicles per env (reference draws 2..11, merge_env_v1.py:180-211) */
 #define MM_N_ACTIONS 5   /* DiscreteMetaAction.ACTIONS_ALL, envs/common/action.py:141-147 */
 #define MM_OBS_ROWS 5    /* KinematicObservation vehicles_count, envs/common/observation.py:132 */
@@ -67,6 +67,8 @@ enum {
   MM_F_H1_VX,        /*   (the shield reads only x and vx of a history record: the heading /   */
   MM_F_H2_X,         /*    speed entries feed dpsi terms that no CBF row uses, cbf.py:206-257)  */
   MM_F_H2_VX,        /* state_hist[-2] (decentral_layer.py:126,175,202)                        */
+  MM_F_STEER_ANGLE,  /* MDPLCVehicle.steering_angle, lateral_control "steer_vel" only
+                        (safe_controller.py:54,124-150); stays 0 and is not touched in "steer" mode */
   MM_F_COUNT
 };
 
@@ -85,6 +87,8 @@ enum {
                        G_VX its MOBIL timer (it has no safe_action / fg_params). */
   MM_B_COUNT
 };
+#define MM_LATERAL_STEER 0
+#define MM_LATERAL_STEER_VEL 1
 #define MM_FLAG_COLLABORATE_ADJ 1u
 #define MM_FLAG_IS_LC_SAFE 2u
 #define MM_FLAG_IS_COLLABORATING 4u
@@ -135,6 +139,10 @@ typedef struct MMConfig {
   int32_t n_hdv;                /* device reset: the last n_hdv of the N vehicles are IDM/MOBIL HDVs
                                    (mixed traffic, merge_env_v1.py:298-362); 0 = CAV-only */
   int32_t agent_reward;         /* config["agent_reward"] (merge_env_v1.py:439-474): 0 default, 1 srew, 2 mrew */
+  int32_t lateral_control;      /* config["lateral_control"] (merge_env_v1.py:499, safe_controller.py:30-44):
+                                   MM_LATERAL_STEER (1st-order, default) | MM_LATERAL_STEER_VEL (steering velocity,
+                                   KP_STEER 20, STEER_TARGET_RF 0.125); v1 CAVs only, as in the reference */
+  int32_t reserved0;
 } MMConfig;
 
 /*
@@ -172,6 +180,10 @@ enum {
   MM_T_LC_MARGIN,                 /* min of the four is_lc_allowed quantities (cbf.py:335-339):
                                      lane change allowed <=> margin >= 0.  Structurally ~0 (sign =
                                      rounding noise) when the adjacent CBF row is the active one */
+  MM_T_STATUS,                    /* MM_ST_* bits of the in-step shield call (is_optimal / is_safe / is_invariant,
+                                     cbf.py:341-357); NaN if the shield did not run                         */
+  MM_T_HEADWAY,                   /* vehicle.min_headway set by the shield: (x_ol - x_e - LENGTH) / vx_e
+                                     (decentral_layer.py:466,700); NaN if the shield did not run             */
   MM_T_COUNT
 };
 

@@ -7,19 +7,19 @@ shared object is loaded is decided by the caller, never silently.
 import ctypes as C
 import os
 
-MM_ABI_VERSION = 3
+MM_ABI_VERSION = 4
 MM_MAX_AGENTS = 16
 ENV_V0, ENV_V1 = 0, 1
 SHIELD_NONE, SHIELD_HSS, SHIELD_MASS = 0, 1, 2
 
 # plane indices (keep in sync with include/mm_abi.h; checked by tests/test_abi.py)
 F_PLANES = ["X", "Y", "HEADING", "SPEED", "TARGET_SPEED", "SAFE_STEER", "SAFE_ACC", "G_VX",
-            "H1_X", "H1_VX", "H2_X", "H2_VX"]
+            "H1_X", "H1_VX", "H2_X", "H2_VX", "STEER_ANGLE"]
 B_PLANES = ["LANE", "TARGET_LANE", "SPEED_INDEX", "CRASHED", "HL_ACTION", "FLAGS", "HIST_LEN", "KIND"]
 E_PLANES = ["STEPS", "TIME", "N_MERGE", "EPISODE"]
 T_PLANES = ["X", "Y", "HEADING", "SPEED", "ACT_STEER", "ACT_ACC", "SAFE_STEER", "SAFE_ACC", "LANE",
             "TARGET_LANE", "CRASHED", "FLAGS", "QP_ROWS", "QP_A", "QP_H0", "QP_H1", "QP_H2", "QP_H3",
-            "QP_D", "LC_MARGIN"]
+            "QP_D", "LC_MARGIN", "STATUS", "HEADWAY"]
 F = {n: i for i, n in enumerate(F_PLANES)}
 B = {n: i for i, n in enumerate(B_PLANES)}
 EP = {n: i for i, n in enumerate(E_PLANES)}
@@ -50,7 +50,8 @@ class MMConfig(C.Structure):
                 ("headway_cost", C.c_double), ("headway_time", C.c_double),
                 ("merging_lane_cost", C.c_double), ("reward_speed_lo", C.c_double),
                 ("reward_speed_hi", C.c_double), ("cbf_eta", C.c_double), ("cbf_tau", C.c_double),
-                ("seed", C.c_uint64), ("n_hdv", C.c_int32), ("agent_reward", C.c_int32)]
+                ("seed", C.c_uint64), ("n_hdv", C.c_int32), ("agent_reward", C.c_int32),
+                ("lateral_control", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class MMStepOut(C.Structure):
@@ -99,8 +100,10 @@ def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs
     c.abi_version = MM_ABI_VERSION
     c.env_kind = ENV_V1 if env_id == "merge-multi-agent-v1" else ENV_V0
     c.shield = shield_from_safety_guarantee(config.get("safety_guarantee")) if c.env_kind == ENV_V1 else SHIELD_NONE
-    if c.env_kind == ENV_V1 and config.get("lateral_control", "steer") != "steer":
-        raise AttributeError("Lateral control: {0} is not supported".format(config.get("lateral_control")))
+    lat = config.get("lateral_control", "steer") if c.env_kind == ENV_V1 else "steer"
+    if lat not in ("steer", "steer_vel"):  # safe_controller.py:181-184
+        raise AttributeError("Lateral control: {0} is not supported".format(lat))
+    c.lateral_control = 1 if lat == "steer_vel" else 0
     c.simulation_frequency = int(config["simulation_frequency"])
     c.policy_frequency = int(config["policy_frequency"])
     c.duration = int(config["duration"])

@@ -47,6 +47,7 @@ class _VehicleView(object):
         return np.array([self._f("X"), self._f("Y")])
 
     heading = property(lambda s: s._f("HEADING"))
+    steering_angle = property(lambda s: s._f("STEER_ANGLE"))  # lateral_control "steer_vel" (safe_controller.py:54)
     speed = property(lambda s: s._f("SPEED"))
     target_speed = property(lambda s: s._f("TARGET_SPEED"))
     crashed = property(lambda s: bool(s._b("CRASHED")))
@@ -85,8 +86,13 @@ class MergeEnvCompat(object):
     n_a = 5
     metadata = {"render.modes": []}
 
-    def __init__(self, env_id="merge-multi-agent-v0", config=None, backend_factory=None, device="cuda:0"):
+    def __init__(self, env_id="merge-multi-agent-v0", config=None, backend_factory=None, device="cuda:0",
+                 store_profile=False):
+        """`store_profile=True` keeps the per-sub-step control profile of every vehicle
+        (`state_hist` / `action_hist`, safe_controller.py:187-227, behavior.py:505-521) -- what
+        MAPPOControlEval.evaluation (marl/mappo.py:420-438) hands to log_profiles; see control_profile()."""
         self.env_id = env_id
+        self.store_profile = bool(store_profile)
         self.config = abi.default_env_config(env_id)
         if config:
             self.config.update(config)
@@ -175,7 +181,8 @@ class MergeEnvCompat(object):
     def _backend(self):
         if self._b is None:
             self._b = self._factory(E=1, N=MAX_VEHICLES, env_id=self.env_id, config=self.config,
-                                    cbf_eta=CBFType.GAMMA_B, cbf_tau=CBFType.TAU, obs_f64=True)
+                                    cbf_eta=CBFType.GAMMA_B, cbf_tau=CBFType.TAU, obs_f64=True,
+                                    trace=self.store_profile)
         return self._b
 
     # -- Env API ------------------------------------------------------------------------------
@@ -206,6 +213,10 @@ class MergeEnvCompat(object):
         self.road = _Road()
         self.controlled_vehicles = [_VehicleView(self, i) for i in range(n_cav)]
         self.road.vehicles = self.controlled_vehicles + [_VehicleView(self, i) for i in range(n_cav, n_all)]
+        for veh in self.road.vehicles:  # MDPLCVehicle.__init__ :46-56 / IDMVehicleHist.__init__
+            veh.state_hist, veh.action_hist, veh.t_step = [], [], 0.0
+            veh.min_headway = 180.0 / 40.0  # PERCEPTION_DIST / MAX_SPEED (:56)
+            veh._sang = 0.0
         return (obs[0, :n].cpu().numpy().astype(np.float64).reshape(n, -1),
                 avail[0, :n].cpu().numpy().astype(np.int64))
 
@@ -224,6 +235,8 @@ class MergeEnvCompat(object):
         act = torch.ones(1, MAX_VEHICLES, dtype=torch.int32)
         act[0, :n] = torch.tensor(action, dtype=torch.int32)
         obs, reward, done, out = b.step(act.to(b.device))
+        if self.store_profile:
+            self._log_profiles(b)
         self.steps += 1
         self.time = int(b.env_i32[abi.EP["TIME"], 0])
         o = {k: v[0].cpu().numpy() for k, v in out.items()}
@@ -245,6 +258,63 @@ class MergeEnvCompat(object):
         if terminal:
             info["merge_percent"] = float(o["merge_percent"])
         return (obs[0, :n].cpu().numpy().astype(np.float64).reshape(n, -1), float(o["reward"]), terminal, info)
+
+    def _log_profiles(self, b):
+        """log_step of every vehicle for the sub-steps the last step ran (from the device trace)."""
+        T = abi.T
+        tr = b.trace[:, :, 0].cpu().numpy()  # [3, planes, MAX_VEHICLES]
+        dt = 1.0 / self.config["simulation_frequency"]
+        is_lc = self.env_id == "merge-multi-agent-v1"
+        steer_vel = is_lc and self.config.get("lateral_control", "steer") == "steer_vel"
+        hl_name = {v: k for k, v in self.ACTIONS_ALL.items()}
+        for k in range(tr.shape[0]):
+            if np.isnan(tr[k, T["X"], 0]):
+                continue  # early exit on a terminal state (abstract.py:529-531)
+            for j, veh in enumerate(self.road.vehicles):
+                g = lambda name: float(tr[k, T[name], j])  # noqa: E731
+                cav = j < self._n
+                veh.t_step += dt
+                h, speed = g("HEADING"), g("SPEED")
+                state_rec = {"presence": 1, "x": g("X"), "y": g("Y"), "vx": speed * np.cos(h), "vy": speed * np.sin(h),
+                             "heading": h, "cos_h": np.cos(h), "sin_h": np.sin(h), "cos_d": 0.0, "sin_d": 0.0, "speed": speed}
+                if cav and is_lc:
+                    ran = not np.isnan(g("STATUS"))
+                    safe = {"steering": g("SAFE_STEER"), "acceleration": g("SAFE_ACC")}
+                    if steer_vel:
+                        veh._sang += safe["steering"] * dt  # safe_controller.py:139
+                        state_rec["steering_angle"] = veh._sang
+                    else:
+                        state_rec["steering_angle"] = g("ACT_STEER")
+                    if ran:
+                        bits = int(g("STATUS"))
+                        state_rec["safe_status"] = {"is_optimal": bool(bits & abi.ST_IS_OPTIMAL), "is_safe": bool(bits & abi.ST_IS_SAFE),
+                                                    "is_invariant": bool(bits & abi.ST_IS_INVARIANT)}
+                        veh.min_headway = g("HEADWAY")
+                    state_rec["t_step"] = veh.t_step
+                    state_rec["headway"] = veh.min_headway
+                    action_rec = dict(safe)
+                    action_rec["ull_acceleration"], action_rec["ull_steering"] = g("ACT_ACC"), g("ACT_STEER")
+                    hl = veh._b("HL_ACTION")
+                    action_rec["lc_action"] = self.ACTIONS_ALL[hl_name[hl]] if hl != abi.HL_NONE else None
+                    if ran:
+                        action_rec["safe_diff"] = {"acceleration": safe["acceleration"] - g("ACT_ACC"),
+                                                   "steering": safe["steering"] - g("ACT_STEER")}
+                    action_rec["t_step"] = veh.t_step
+                elif is_lc:  # IDMVehicleHist.log_step behavior.py:509-521
+                    state_rec["steering_angle"] = g("ACT_STEER")
+                    state_rec["t_step"] = veh.t_step
+                    action_rec = {"steering": g("ACT_STEER"), "acceleration": g("ACT_ACC"), "t_step": veh.t_step}
+                else:
+                    continue  # v0 vehicles (MDPVehicle / IDMVehicle) keep no profile
+                veh.state_hist.append(state_rec)
+                veh.action_hist.append(action_rec)
+
+    def control_profile(self):
+        """ext_info["control_profile"] of MAPPOControlEval.evaluation (marl/mappo.py:424-437)."""
+        cp = {}
+        for j, veh in enumerate(self.road.vehicles):
+            cp[("av" if j < self._n else "hdv") + str(veh.id)] = {"state_hist": veh.state_hist, "action_hist": veh.action_hist}
+        return cp
 
     def is_crashed(self):
         return any(v.crashed for v in self.controlled_vehicles)

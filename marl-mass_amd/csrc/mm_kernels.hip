@@ -33,6 +33,7 @@ struct DevCfg {
   double rs_lo, rs_hi, eta, tau;
   double inv_dt, rs_span, rs_ispan, rs_span2, rs_ispan2;  // host-computed reciprocals for div_c (correctly rounded 1/d)
   int agent_reward;
+  int steer_vel;  // lateral_control == "steer_vel" (v1 CAVs; handled by the MIXED = general instantiations)
 };
 struct DevState {
   double *F;
@@ -42,6 +43,14 @@ struct DevState {
   long long A;
   int E, N;
 };
+
+// Translation units.  The library is built from this one source compiled twice (Makefile):
+//   MM_TU=1  everything except the "general" step kernels (MIXED = true: HDVs and/or steer_vel),
+//   MM_TU=2  only those, with conservative SGPR spilling (DESIGN.md "toolchain note").
+// MM_TU=0 (default) is the single-TU form used by the tuning / diagnostic builds.
+#ifndef MM_TU
+#define MM_TU 0
+#endif
 
 // Diagnostic build only (-DMM_STAMPS): per-phase cycle sums (s_memtime) accumulated by lane 0 of each
 // wave into a __device__ array the host reads with mm_debug_read_stamps.  Never in the product build.
@@ -61,6 +70,7 @@ struct Veh {
   double x, y, h, v, tspeed;
   double act_steer, act_acc, safe_steer, safe_acc, gvx;
   double h1x, h1vx, h2x, h2vx;  // x / vx of state_hist[-1], [-2]
+  double sang;                  // MDPLCVehicle.steering_angle ("steer_vel" lateral control only)
   int lane, tlane, sidx, crashed, hl, flags, hist_len;
   int kind;  // 0 absent, 1 controlled CAV, 2 HDV (for an HDV `gvx` holds the MOBIL timer, see mm_abi.h)
   bool present;
@@ -133,7 +143,7 @@ MM_DEV double group_min_d(double v) {
 // ------------------------------------------------------------------------------------------------
 // state load / store
 // ------------------------------------------------------------------------------------------------
-MM_DEV void load_veh(const DevState &st, long long i, bool valid, Veh &v) {
+MM_DEV void load_veh(const DevState &st, long long i, bool valid, Veh &v, bool with_sang = false) {
   memset(&v, 0, sizeof v);
   v.present = false;
   v.hl = MM_HL_NONE;
@@ -153,9 +163,11 @@ MM_DEV void load_veh(const DevState &st, long long i, bool valid, Veh &v) {
   v.hl = st.B[MM_B_HL_ACTION * A + i]; v.flags = st.B[MM_B_FLAGS * A + i];
   v.hist_len = st.B[MM_B_HIST_LEN * A + i];
   if (v.kind == 2) { v.act_steer = v.safe_steer; v.act_acc = v.safe_acc; }  // last IDM action persists
+  if (with_sang) v.sang = st.F[MM_F_STEER_ANGLE * A + i];
 }
-MM_DEV void store_veh(const DevState &st, long long i, const Veh &v) {
+MM_DEV void store_veh(const DevState &st, long long i, const Veh &v, bool with_sang = false) {
   const long long A = st.A;
+  if (with_sang) st.F[MM_F_STEER_ANGLE * A + i] = v.sang;
   st.F[MM_F_X * A + i] = v.x; st.F[MM_F_Y * A + i] = v.y; st.F[MM_F_HEADING * A + i] = v.h;
   st.F[MM_F_SPEED * A + i] = v.v; st.F[MM_F_TARGET_SPEED * A + i] = v.tspeed;
   st.F[MM_F_SAFE_STEER * A + i] = v.kind == 2 ? v.act_steer : v.safe_steer;
@@ -173,7 +185,10 @@ MM_DEV void store_veh(const DevState &st, long long i, const Veh &v) {
 // per-vehicle control (controller.py)
 // ------------------------------------------------------------------------------------------------
 // controller.py:90-134 ControlledVehicle.act; action 0 LEFT / 2 RIGHT change lanes, else none
-MM_DEV void controlled_act(Veh &v, int action) {
+// safe_controller.py:84-98 MDPLCVehicle.steering_control in "steer_vel" mode: a steering VELOCITY that
+// tracks the scaled-down reference angle (KP_STEER 20, STEER_TARGET_RF 0.125)
+MM_DEV double steer_vel_command(double steering_ref, double sang) { return 20 * (steering_ref * 0.125 - sang); }
+MM_DEV void controlled_act(Veh &v, int action, bool sv = false) {
   if (lane_after_end(v.tlane, v.x)) v.tlane = next_lane(v.tlane, v.x, v.y);  // follow_road :136-144
   if (action == 2 || action == 0) {
     // only road (b,c) has two lanes; elsewhere the clipped candidate is the lane itself
@@ -182,6 +197,7 @@ MM_DEV void controlled_act(Veh &v, int action) {
     if (lane_reachable(cand, v.x, v.y)) v.tlane = cand;
   }
   double steer = steering_control(v.x, v.y, v.h, v.v, v.tlane);
+  if (sv) steer = steer_vel_command(steer, v.sang);
   v.act_acc = (1 / kTauA) * (v.tspeed - v.v);  // speed_control :189-197
   v.act_steer = clipd(steer, -kPi / 3, kPi / 3);
 }
@@ -236,13 +252,16 @@ struct Cand {
   bool offL, offR;
 };
 template <int KIND, bool SHIELDED>
-MM_DEV Cand predict(const Veh &v, double steer, double dt) {
+MM_DEV Cand predict(const Veh &v, double steer, double dt, bool sv = false) {
   Cand c;
-  double beta = mmm_atan(1.0 / 2 * mmm_tan(steer));
+  // "steer_vel" (safe_controller.py:124-150): the slip angle comes from the steering-angle STATE and the
+  // heading advances by d_heading without the dt factor (sic, :135)
+  double beta = mmm_atan(1.0 / 2 * mmm_tan(sv ? v.sang : steer));
   double vx = v.v * mmm_cos(v.h + beta), vy = v.v * mmm_sin(v.h + beta);
   c.x = v.x + vx * dt;
   c.y = v.y + vy * dt;
-  c.h = v.h + MM_DIVC(v.v * mmm_sin(beta), 2.5) * dt;  // / (LENGTH / 2)
+  const double d_heading = MM_DIVC(v.v * mmm_sin(beta), 2.5);  // / (LENGTH / 2)
+  c.h = v.h + (sv ? d_heading : d_heading * dt);
   c.gvx = (KIND == MM_ENV_V1) ? mmm_cos(c.h + beta) : 0.0;
   c.lane = closest_lane(c.x, c.y, c.h);  // on_state_update kinematics.py:154-159
   c.cpsi = (KIND == MM_ENV_V1) ? mmm_cos(c.h) : 0.0;
@@ -288,6 +307,7 @@ MM_DEV void init_vehicle(Veh &v) {  // kinematics.py:36-53, controller.py:35-50,
     v.gvx = __builtin_nan("");
   }
   v.h1x = v.h1vx = v.h2x = v.h2vx = 0;
+  v.sang = 0;  // safe_controller.py:54
   v.crashed = 0; v.hl = MM_HL_NONE; v.flags = 0; v.hist_len = 0;
 }
 MM_DEV int spawn_vehicle(Veh &v, int a, int n_cav, int n_hdv, uint64_t seed, uint32_t episode) {
@@ -374,6 +394,10 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
       if (m2 != m) rank += (key[m2] < key[m] || (key[m2] == key[m] && (a ^ m2) < (a ^ m))) ? 1 : 0;
     double px = dppx_d<m>(v.x), py = dppx_d<m>(v.y), pvx = dppx_d<m>(vx), pvy = dppx_d<m>(vy);
     double ph = (KIND == MM_ENV_V1) ? dppx_d<m>(v.h) : 0.0;
+    if (KIND == MM_ENV_V1 && c.steer_vel) {  // MDPLCVehicle.to_dict under "steer_vel" (safe_controller.py:75-81):
+      const int pkind = dppx_i<m>(v.kind);   // a CAV neighbour's heading is relative to the observer's
+      if (pkind == 1) ph = ph - v.h;
+    }
     bool use = key[m] < INFINITY;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -515,6 +539,7 @@ struct ShieldOut {
   double acc, us0;  // derived acceleration, u_safe[0]
   bool veto;        // "Avoiding lane change" (:501-506 / :739-744)
   bool lon_safe, lon_invariant;  // CBF_AV.update_status cbf.py:341-351
+  double headway;                // vehicle.set_min_headway (decentral_layer.py:466,700); trace only
   int flags;
   QpTrace qt;
 };
@@ -612,6 +637,7 @@ MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s
     const double hlds_lon = s.px_lon + ((-s.g0) * us0 + s.g2 * u2) + s.q_lon;
     o.lon_safe = hls_lon >= -1e-6;
     o.lon_invariant = (hlds_lon + (eta - 1) * hls_lon) >= -1e-6;
+    o.headway = (s.px_lon - kVehLength) / s.evx;
   }
   // is_lc_allowed (cbf.py:324-339)
   const double hlds_lona = s.px_lona + ((-s.g0) * us0 + s.g4 * u4) + s.q_lona;
@@ -674,6 +700,14 @@ MM_DEV Rel relate(double ex, double ey, int elane, int enl, bool other, double o
   return r;
 }
 
+// trace of the in-step shield call's status dict and min_headway (written where they are produced so that
+// they need not stay in registers)
+MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
+  t[MM_T_STATUS * A] = (double)(MM_ST_RAN | MM_ST_IS_OPTIMAL | (o.lon_safe ? MM_ST_IS_SAFE : 0u) |
+                                (o.lon_invariant ? MM_ST_IS_INVARIANT : 0u));
+  t[MM_T_HEADWAY * A] = o.headway;
+}
+
 // ------------------------------------------------------------------------------------------------
 // the fused step kernel
 // ------------------------------------------------------------------------------------------------
@@ -705,7 +739,8 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
   unsigned long long _t_last = __builtin_amdgcn_s_memtime();
 #endif
   Veh v;
-  load_veh(st, i, valid, v);
+  const bool sv = MIXED && KIND == MM_ENV_V1 && c.steer_vel != 0;
+  load_veh(st, i, valid, v, sv);
   int steps = 0, time = 0, n_merge = 0, episode = 0;
   if (e < st.E) {
     steps = st.I[MM_E_STEPS * st.E + e]; time = st.I[MM_E_TIME * st.E + e];
@@ -764,7 +799,7 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
       if (time % c.nsub == 0) hl_act<KIND>(v, action);  // action_type.act abstract.py:516-519
     }
     const int tl_pre = v.tlane;  // what an HDV acting before this vehicle still sees
-    if (live && !hdv) controlled_act(v, -1);  // road.act road.py:269-278
+    if (live && !hdv) controlled_act(v, -1, sv);  // road.act road.py:269-278
     s_cold[C_TSPEED][tid] = v.tspeed;
     if constexpr (MIXED) {
       // ---------------- IDMVehicle.act for the HDVs (behavior.py:74-100) -------------------------
@@ -857,7 +892,7 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
     Cand cA;
     memset(&cA, 0, sizeof cA);
     const bool shield_on = SHIELDED && live && !hdv && v.hist_len >= 2;  // gate safe_controller.py:232-239
-    if (live) cA = predict<KIND, SHIELDED>(v, v.act_steer, dt);
+    if (live) cA = predict<KIND, SHIELDED>(v, v.act_steer, dt, sv && !hdv);
     auto park = [&](int base, const Cand &cc, double steer) {  // a candidate's LDS image
       s_cold[base + 0][tid] = cc.x; s_cold[base + 1][tid] = cc.y; s_cold[base + 2][tid] = cc.h;
       s_cold[base + 3][tid] = cc.gvx; s_cold[base + 4][tid] = cc.cpsi; s_cold[base + 5][tid] = steer;
@@ -868,33 +903,27 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
     // LC veto re-steers to the CURRENT lane (decentral_layer.py:501-506,739-744); identical to the
     // nominal command unless a lane change / lane hand-over is under way or the car crashed.
     // Candidate B is only predicted when a veto actually fires (lazily, below).
-    const bool needB = SHIELDED && shield_on && (v.tlane != v.lane || v.crashed);
+    // ("steer_vel": the veto's velocity command is not clipped to +-pi/3 like the nominal one, so it can
+    // differ even without a lane change)
+    const bool needB = SHIELDED && shield_on && (v.tlane != v.lane || v.crashed || sv);
     bool haveB = false;
     auto make_B = [&]() {
       if (SHIELDED && needB && !haveB) {
-        const double steerB = steering_control(v.x, v.y, v.h, v.v, v.lane);
-        park(C_B, predict<KIND, true>(v, steerB, dt), steerB);
+        double steerB = steering_control(v.x, v.y, v.h, v.v, v.lane);
+        if (sv) steerB = steer_vel_command(steerB, v.sang);
+        park(C_B, predict<KIND, true>(v, steerB, dt, sv), steerB);
         haveB = true;
       }
     };
     // the candidate a vehicle commits / shows to later vehicles: A, or B (from LDS) after a veto
     auto chosen = [&](bool useB) {
       if (!SHIELDED) return cA;
-#ifdef MM_T_REGA
-      if (!useB) return cA;
-#endif
       const int base = useB ? C_B : C_A;  // both candidates sit in LDS; A's registers are free meanwhile
       Cand cc;
       cc.x = s_cold[base + 0][tid]; cc.y = s_cold[base + 1][tid]; cc.h = s_cold[base + 2][tid];
       cc.gvx = s_cold[base + 3][tid]; cc.cpsi = s_cold[base + 4][tid];
       const int pk = (int)s_cold[base + 6][tid];
       cc.lane = pk & 7; cc.nl = (pk >> 3) & 7; cc.offL = ((pk >> 6) & 1) != 0; cc.offR = ((pk >> 7) & 1) != 0;
-#ifdef MM_T_REGPK
-      if (!useB) { cc.lane = cA.lane; cc.nl = cA.nl; cc.offL = cA.offL; cc.offR = cA.offR; }
-#endif
-#ifdef MM_T_REGPOSE
-      if (!useB) { cc.x = cA.x; cc.y = cA.y; cc.h = cA.h; cc.gvx = cA.gvx; cc.cpsi = cA.cpsi; }
-#endif
       return cc;
     };
     double new_acc = v.act_acc;
@@ -1009,10 +1038,8 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
             acc_cur = acc_next;
             if (!MASS || !__any(changed)) break;
           }
+          if (out.trace && shield_on) trace_status(out.trace + (long long)k * MM_T_COUNT * A + i, A, so);
           STAMP(4);  // selection + fixed-point rounds
-#ifdef MM_DBGPRINT
-          if (e == 0 && k == 2) printf("PAR a=%d pass=%d rank=%d j_ol=%d j_oa=%d j_oar=%d has=%d%d%d ol_dyn=%d olx=%.9f olvx=%.9f olacc=%.9f olg=%.9f acc=%.9f h0=%.9f son=%d irr=%d\n", a, pass, rank, j_ol, j_oa, j_oar, (int)nb.has_ol, (int)nb.has_oa, (int)nb.has_oar, (int)ol_dyn, nb.ol_x, nb.ol_vx, nb.ol_acc, nb.ol_g, so.acc, so.qt.h0, (int)shield_on, (int)irregular);
-#endif
           const bool want_B = shield_on && so.veto && needB;
           if (want_B) make_B();
           STAMP(5);  // lazy candidate B
@@ -1112,10 +1139,8 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
           if (hss_collab) s1.flags |= MM_FLAG_IS_COLLABORATING;  // vehicle.is_collaborating = cbf.constrain_adj
           if (has && a == ai && shield_on) {
             new_acc = s1.acc; veto = s1.veto; new_flags = s1.flags; qt = s1.qt;
+            if (out.trace) trace_status(out.trace + (long long)k * MM_T_COUNT * A + i, A, s1);
             use_B = veto && needB;
-#ifdef MM_DBGPRINT
-            if (e == 0 && k == 2) printf("SER a=%d rank=%d has=%d%d%d olx=%.9f olvx=%.9f olacc=%.9f olg=%.9f acc=%.9f h0=%.9f\n", a, rank, (int)nb.has_ol, (int)nb.has_oa, (int)nb.has_oar, nb.ol_x, nb.ol_vx, nb.ol_acc, nb.ol_g, s1.acc, s1.qt.h0);
-#endif
             const Cand cc = chosen(use_B);
             double nv = v.v + new_acc * dt;
             nv = nv > 0 ? nv : 0;
@@ -1151,6 +1176,7 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
           // a veto re-steers to the current lane; identical to the nominal command unless B was needed
           s_cold[C_SSTEER][tid] = (SHIELDED && shield_on && veto && haveB) ? s_cold[C_B + 5][tid] : v.act_steer;
           s_cold[C_SACC][tid] = acc; v.gvx = cc.gvx;
+          if (sv) v.sang += s_cold[C_SSTEER][tid] * dt;  // steering_angle += safe steering velocity * dt (:139)
         }
         s_cold[C_H2X][tid] = s_cold[C_H1X][tid]; s_cold[C_H2VX][tid] = s_cold[C_H1VX][tid];  // log_step :187-201 (IDMVehicleHist: behavior.py:505-521)
         s_cold[C_H1X][tid] = v.x; s_cold[C_H1VX][tid] = v.v * cc.cpsi;
@@ -1377,7 +1403,7 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
       if (!hdv) { v.safe_steer = s_cold[C_SSTEER][tid]; v.safe_acc = s_cold[C_SACC][tid]; }
     }
     v.tspeed = s_cold[C_TSPEED][tid];
-    store_veh(st, i, v);
+    store_veh(st, i, v, sv);
   }
   if (e < st.E && a == 0) {
     st.I[MM_E_STEPS * st.E + e] = steps; st.I[MM_E_TIME * st.E + e] = time;
@@ -1385,11 +1411,7 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
   }
   STAMP(11);  // re-spawn + state store
   __syncthreads();  // every wave is done with its cold slots: the obs staging below reuses that LDS
-#ifdef MM_T_NOLEND
-  observe<G, KIND>(c, v, a, gb, i, valid, out.obs, out.action_mask);
-#else
   observe<G, KIND, true>(c, v, a, gb, i, valid, out.obs, out.action_mask, (float *)&s_cold[0][0]);
-#endif
   STAMP(12);  // observation
 }
 
@@ -1424,7 +1446,7 @@ __global__ __launch_bounds__(256) void reset_kernel(DevCfg c, DevState st, int m
       if (valid && v.present) init_vehicle(v);
       n_merge = __popc(group_ballot<G>(valid && v.kind == 1 && (v.lane == MM_LANE_JK0 || v.lane == MM_LANE_KB0), gb));
     }
-    if (valid && v.present) store_veh(st, i, v);
+    if (valid && v.present) store_veh(st, i, v, true);
     if (a == 0) {
       st.I[MM_E_STEPS * st.E + e] = steps; st.I[MM_E_TIME * st.E + e] = time;
       st.I[MM_E_N_MERGE * st.E + e] = n_merge; st.I[MM_E_EPISODE * st.E + e] = episode;
@@ -1449,7 +1471,7 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
   const bool valid = e < st.E && a < st.N;
   const long long i = e * st.N + a;
   Veh v;
-  load_veh(st, i, valid, v);
+  load_veh(st, i, valid, v, c.steer_vel != 0);
   const bool hdv = v.kind == 2;
   const bool ctrl = v.present && !hdv;
   if (valid) { v.act_steer = act_steer[i]; v.act_acc = act_acc[i]; }
@@ -1537,7 +1559,10 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
     unsigned stt = 0;
     if (on) {
       sa = so.acc;
-      if (so.veto) ss = steering_control(v.x, v.y, v.h, v.v, v.lane);  // target_lane_index = lane_index (:501-506)
+      if (so.veto) {  // target_lane_index = lane_index (:501-506)
+        ss = steering_control(v.x, v.y, v.h, v.v, v.lane);
+        if (c.steer_vel) ss = steer_vel_command(ss, v.sang);
+      }
       stt = MM_ST_RAN | MM_ST_IS_OPTIMAL | (so.lon_safe ? MM_ST_IS_SAFE : 0u) | (so.lon_invariant ? MM_ST_IS_INVARIANT : 0u) |
             ((so.flags & MM_FLAG_IS_LC_SAFE) ? MM_ST_IS_LC_SAFE : 0u) |
             ((so.flags & MM_FLAG_IS_COLLABORATING) ? MM_ST_IS_COLLABORATING : 0u) |
@@ -1550,6 +1575,7 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
 }
 
 // stand-alone batched shield QP (cbf.py:110-161): exact KKT point, one thread per QP
+#if MM_TU != 2
 __global__ void qp_kernel(int n, const double *__restrict__ G, const double *__restrict__ h,
                           const int32_t *__restrict__ rows, double *__restrict__ u, uint8_t *status) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1567,6 +1593,8 @@ __global__ void qp_kernel(int n, const double *__restrict__ G, const double *__r
   if (status) status[k] = 1;
 }
 
+#endif  // MM_TU != 2
+
 // ------------------------------------------------------------------------------------------------
 // host side: C ABI
 // ------------------------------------------------------------------------------------------------
@@ -1580,6 +1608,7 @@ struct MMHandle_ {
   char err[256];
 };
 
+#if MM_TU != 2
 static uint64_t align256(uint64_t x) { return (x + 255u) & ~(uint64_t)255u; }
 
 extern "C" int32_t mm_abi_version(void) { return MM_ABI_VERSION; }
@@ -1645,6 +1674,7 @@ extern "C" int32_t mm_set_metrics_buffer(MMHandle h, double *metrics) {
   return MM_OK;
 }
 extern "C" const char *mm_last_error(MMHandle h) { return h ? h->err : "null handle"; }
+#endif  // MM_TU != 2
 
 static DevCfg dev_cfg(const MMHandle h) {
   const MMConfig &c = h->cfg;
@@ -1660,6 +1690,7 @@ static DevCfg dev_cfg(const MMHandle h) {
   d.inv_dt = 1.0 / d.dt; d.rs_span = d.rs_hi - d.rs_lo; d.rs_ispan = 1.0 / d.rs_span;
   d.rs_span2 = (d.rs_lo + (d.rs_hi - d.rs_lo) / 2) - d.rs_lo; d.rs_ispan2 = 1.0 / d.rs_span2;  // mrew, collaborating
   d.agent_reward = c.env_kind == MM_ENV_V1 ? c.agent_reward : 0;
+  d.steer_vel = (c.env_kind == MM_ENV_V1 && c.lateral_control == MM_LATERAL_STEER_VEL) ? 1 : 0;
   return d;
 }
 static DevState dev_state(const MMHandle h) {
@@ -1671,6 +1702,7 @@ static DevState dev_state(const MMHandle h) {
 }
 static int group_size(int N) { return N <= 2 ? 2 : (N <= 4 ? 4 : (N <= 8 ? 8 : 16)); }
 
+#if MM_TU != 2
 template <int G, int KIND>
 static void launch_reset_t(MMHandle h, int mode, const uint8_t *mask, const uint64_t *seeds, void *obs,
                            uint8_t *avail, hipStream_t s) {
@@ -1716,6 +1748,8 @@ extern "C" int32_t mm_observe(MMHandle h, void *obs, uint8_t *avail, MMStream st
   return launch_reset(h, 2, nullptr, nullptr, obs, avail, stream);
 }
 
+#endif  // MM_TU != 2
+
 template <int G, int KIND, int SHIELD, bool MIXED>
 static void launch_step_t(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   const long long threads = (long long)h->E * G;
@@ -1738,12 +1772,30 @@ static void launch_step_m(MMHandle h, const int32_t *actions, const MMStepOut *o
 }
 // mixed traffic (cfg.n_hdv > 0) runs the kernels that carry the IDM/MOBIL code; CAV-only batches
 // keep the leaner instantiation
+#if MM_TU != 0
+void mm_launch_step_general(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s);
+#endif
+#if MM_TU == 2
+void mm_launch_step_general(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+  switch (group_size(h->N)) {
+    case 2: launch_step_m<2, true>(h, actions, out, s); break;
+    case 4: launch_step_m<4, true>(h, actions, out, s); break;
+    case 8: launch_step_m<8, true>(h, actions, out, s); break;
+    default: launch_step_m<16, true>(h, actions, out, s); break;
+  }
+}
+#else
 template <int G>
 static void launch_step_g(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
 #ifdef MM_ONLY_MIXED  // tuning builds
   launch_step_m<G, MM_ONLY_MIXED>(h, actions, out, s);
 #else
-  if (h->cfg.n_hdv > 0) launch_step_m<G, true>(h, actions, out, s);
+  if (h->cfg.n_hdv > 0 || (h->cfg.env_kind == MM_ENV_V1 && h->cfg.lateral_control == MM_LATERAL_STEER_VEL))
+#if MM_TU == 1
+    mm_launch_step_general(h, actions, out, s);
+#else
+    launch_step_m<G, true>(h, actions, out, s);
+#endif
   else launch_step_m<G, false>(h, actions, out, s);
 #endif
 }
@@ -1849,3 +1901,4 @@ extern "C" int32_t mm_debug_read_stamps(unsigned long long *out16, int32_t reset
   return rc == hipSuccess ? MM_OK : MM_ERR_DEVICE;
 }
 #endif
+#endif  // MM_TU != 2

@@ -88,10 +88,13 @@ typedef struct {
   double h1[2], h2[2];         /* state_hist[-1], [-2]: x, vx (all the shield reads of a record) */
   int lane, target_lane, speed_index, crashed, hl_action, flags, hist_len, kind; /* kind: 1 CAV, 2 HDV */
   double timer;                /* IDMVehicle.timer (behavior.py:53) */
+  double steer_angle;          /* MDPLCVehicle.steering_angle (safe_controller.py:54) */
+  int steer_vel;               /* lateral_ctrl == "steer_vel" on this (MDPLC) vehicle (:44) */
   double local_reward, regional_reward;
   /* trace of the last shield call */
   double qp_rows, qp_a, qp_h[4], qp_d, lc_margin;
   int lon_safe, lon_invariant; /* CBF_AV.update_status cbf.py:341-351 */
+  double shield_headway;       /* vehicle.min_headway as the last shield call set it */
 } Veh;
 
 typedef struct {
@@ -276,6 +279,16 @@ static double steering_control(const Veh *v, int target_lane) {
       m_asin(clipd(VEH_LENGTH / 2 / not_zero(v->speed) * heading_rate_command, -1, 1));
   return clipd(steering_angle, -MAX_STEER, MAX_STEER);
 }
+/* safe_controller.py:84-98 MDPLCVehicle.steering_control: in "steer_vel" mode the command is a
+ * steering VELOCITY tracking a scaled-down reference angle (KP_STEER 20, STEER_TARGET_RF 0.125) */
+static double lc_steering_control(const Veh *v, int target_lane) {
+  double steering_ref = steering_control(v, target_lane);
+  if (v->steer_vel) {
+    steering_ref = steering_ref * 0.125;
+    return 20 * (steering_ref - v->steer_angle);
+  }
+  return steering_ref;
+}
 /* controller.py:189-197 */
 static double speed_control(const Veh *v, double target_speed) {
   return (1 / TAU_A) * (target_speed - v->speed);
@@ -292,7 +305,7 @@ static void controlled_act(Veh *v, int action) {
     int cand = (road == 1) ? (nid == 1 ? MM_LANE_BC1 : MM_LANE_BC0) : v->target_lane;
     if (lane_is_reachable_from(cand, v->x, v->y)) v->target_lane = cand;
   }
-  double steer = steering_control(v, v->target_lane);
+  double steer = lc_steering_control(v, v->target_lane);
   v->act_acc = speed_control(v, v->target_speed);
   v->act_steer = clipd(steer, -PI / 3, PI / 3);
 }
@@ -597,6 +610,7 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
   sv_oar = sv_oar > 1 ? sv_oar : 1;
   double buffer = (CBF_ACC_HI + 0.1) * dt * TAU;
   double sd0 = s_e.vx * TAU + VEH_LENGTH + buffer;
+  veh->shield_headway = (sf_ol[0] - s_e.x - VEH_LENGTH) / s_e.vx; /* set_min_headway :466 / :700 */
   double sd1 = sd0;
   double sd2 = sv_oar * TAU + VEH_LENGTH + buffer;
 
@@ -665,7 +679,7 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
   if (!mass) {
     if (!lc_allowed) { /* :501-506 */
       veh->target_lane = veh->lane;
-      u_safe1 = steering_control(veh, veh->target_lane);
+      u_safe1 = lc_steering_control(veh, veh->target_lane);
       flags &= ~MM_FLAG_IS_LC_SAFE;
     }
   } else {
@@ -677,7 +691,7 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
     can_abort_lc = can_abort_lc && lane_on_lane(veh->lane, cx, cy);
     if (can_abort_lc && !lc_allowed) { /* :739-744 */
       veh->target_lane = veh->lane;
-      u_safe1 = steering_control(veh, veh->target_lane);
+      u_safe1 = lc_steering_control(veh, veh->target_lane);
       flags &= ~MM_FLAG_IS_LC_SAFE;
     } else if ((veh->hl_action == 2 || veh->hl_action == 0) && veh->speed < STOPPING_SPEED) {
       u_safe0 = u[0]; /* :746-750 */
@@ -716,13 +730,26 @@ static int vehicle_step(const MMConfig *cfg, Env *e, int i, double dt) {
   if (is_lc && cfg->shield != MM_SHIELD_NONE && v->hist_len >= 2) /* gate :232-239 */
     rc = safety_layer(cfg, e, i, dt, &acc, &steer);
   if (is_lc) { v->safe_steer = steer; v->safe_acc = acc; }
-  double beta = m_atan(1.0 / 2 * m_tan(steer));
-  double vx = v->speed * m_cos(v->heading + beta);
-  double vy = v->speed * m_sin(v->heading + beta);
-  v->x += vx * dt;
-  v->y += vy * dt;
-  v->heading += v->speed * m_sin(beta) / (VEH_LENGTH / 2) * dt;
-  v->speed += acc * dt;
+  double beta;
+  if (is_lc && v->steer_vel) { /* safe_controller.py:124-150: 2nd-order steering response */
+    beta = m_atan(1.0 / 2 * m_tan(v->steer_angle));
+    double vx = v->speed * m_cos(v->heading + beta);
+    double vy = v->speed * m_sin(v->heading + beta);
+    v->x += vx * dt;
+    v->y += vy * dt;
+    double d_heading = v->speed * m_sin(beta) / (VEH_LENGTH / 2);
+    v->heading += d_heading; /* sic: no dt (:135) */
+    v->speed += acc * dt;
+    v->steer_angle += steer * dt;
+  } else {
+    beta = m_atan(1.0 / 2 * m_tan(steer));
+    double vx = v->speed * m_cos(v->heading + beta);
+    double vy = v->speed * m_sin(v->heading + beta);
+    v->x += vx * dt;
+    v->y += vy * dt;
+    v->heading += v->speed * m_sin(beta) / (VEH_LENGTH / 2) * dt;
+    v->speed += acc * dt;
+  }
   v->speed = v->speed > 0 ? v->speed : 0; /* max(0, speed) */
   if (is_lc) v->g_vx = m_cos(v->heading + beta);
   v->lane = closest_lane(v->x, v->y, v->heading); /* on_state_update kinematics.py:154-159 */
@@ -810,6 +837,11 @@ static int simulate(const MMConfig *cfg, Env *e, const int32_t *actions, double 
         t[MM_T_QP_H0 * A] = v->qp_h[0]; t[MM_T_QP_H1 * A] = v->qp_h[1];
         t[MM_T_QP_H2 * A] = v->qp_h[2]; t[MM_T_QP_H3 * A] = v->qp_h[3];
         t[MM_T_QP_D * A] = v->qp_d; t[MM_T_LC_MARGIN * A] = v->lc_margin;
+        if (v->qp_rows > 0) {
+          t[MM_T_STATUS * A] = (double)(MM_ST_RAN | MM_ST_IS_OPTIMAL | (v->lon_safe ? MM_ST_IS_SAFE : 0) |
+                                        (v->lon_invariant ? MM_ST_IS_INVARIANT : 0));
+          t[MM_T_HEADWAY * A] = v->shield_headway;
+        }
       }
     }
     if (is_terminal(cfg, e)) break;
@@ -836,6 +868,9 @@ static void observe_agent(const MMConfig *cfg, const Env *e, int i, double *out)
     double ovx = o->speed * m_cos(o->heading), ovy = o->speed * m_sin(o->heading);
     rows[nrows][0] = 1; rows[nrows][1] = o->x - me->x; rows[nrows][2] = o->y - me->y;
     rows[nrows][3] = ovx - evx; rows[nrows][4] = ovy - evy; rows[nrows][5] = o->heading;
+    /* MDPLCVehicle.to_dict under "steer_vel": a neighbour's heading is taken relative to the observer's
+     * (safe_controller.py:75-81); IDM vehicles use the base to_dict and stay absolute */
+    if (o->steer_vel) rows[nrows][5] = o->heading - me->heading;
     nrows++;
   }
   /* normalize_obs :181-193 with utils.lmap :16-18; ranges :171-176, :238-239; clip=False */
@@ -1010,6 +1045,7 @@ static void init_vehicle(Veh *v) {
   v->act_steer = v->act_acc = 0;
   v->safe_steer = v->safe_acc = 0;
   v->g_vx = NAN; /* fg_params = None */
+  v->steer_angle = 0; /* safe_controller.py:54 */
   memset(v->h1, 0, sizeof v->h1);
   memset(v->h2, 0, sizeof v->h2);
   v->crashed = 0; v->hl_action = MM_HL_NONE; v->flags = 0; v->hist_len = 0;
@@ -1071,12 +1107,14 @@ static void load_env(const struct MMHandle_ *h, int64_t e_idx, Env *e) {
     v->speed = F[MM_F_SPEED * A + i]; v->target_speed = F[MM_F_TARGET_SPEED * A + i];
     v->safe_steer = F[MM_F_SAFE_STEER * A + i]; v->safe_acc = F[MM_F_SAFE_ACC * A + i];
     v->g_vx = F[MM_F_G_VX * A + i];
+    v->steer_angle = F[MM_F_STEER_ANGLE * A + i];
     for (int k = 0; k < 2; k++) { v->h1[k] = F[(MM_F_H1_X + k) * A + i]; v->h2[k] = F[(MM_F_H2_X + k) * A + i]; }
     v->lane = B[MM_B_LANE * A + i]; v->target_lane = B[MM_B_TARGET_LANE * A + i];
     v->speed_index = B[MM_B_SPEED_INDEX * A + i]; v->crashed = B[MM_B_CRASHED * A + i];
     v->hl_action = B[MM_B_HL_ACTION * A + i]; v->flags = B[MM_B_FLAGS * A + i];
     v->hist_len = B[MM_B_HIST_LEN * A + i]; v->kind = B[MM_B_KIND * A + i];
     if (v->kind == 1 && e->n_ctrl == e->n - 1) e->n_ctrl = e->n; /* controlled vehicles are a prefix */
+    v->steer_vel = v->kind == 1 && h->cfg.env_kind == MM_ENV_V1 && h->cfg.lateral_control == MM_LATERAL_STEER_VEL;
     if (v->kind == 2) { /* HDV: the SAFE_* planes persist its last IDM action, G_VX its MOBIL timer */
       v->act_steer = v->safe_steer; v->act_acc = v->safe_acc; v->timer = v->g_vx;
     }
@@ -1098,6 +1136,7 @@ static void store_env(struct MMHandle_ *h, int64_t e_idx, const Env *e) {
     F[MM_F_SAFE_STEER * A + i] = v->kind == 2 ? v->act_steer : v->safe_steer;
     F[MM_F_SAFE_ACC * A + i] = v->kind == 2 ? v->act_acc : v->safe_acc;
     F[MM_F_G_VX * A + i] = v->kind == 2 ? v->timer : v->g_vx;
+    F[MM_F_STEER_ANGLE * A + i] = v->steer_angle;
     for (int k = 0; k < 2; k++) { F[(MM_F_H1_X + k) * A + i] = v->h1[k]; F[(MM_F_H2_X + k) * A + i] = v->h2[k]; }
     B[MM_B_LANE * A + i] = (uint8_t)v->lane; B[MM_B_TARGET_LANE * A + i] = (uint8_t)v->target_lane;
     B[MM_B_SPEED_INDEX * A + i] = (uint8_t)v->speed_index; B[MM_B_CRASHED * A + i] = (uint8_t)v->crashed;

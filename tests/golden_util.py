@@ -25,8 +25,9 @@ FLOAT_TOL = 1e-5  # north_star: "within 1e-5 on float state"
 
 def episode_files(pattern="*_*.npz"):
     """ep_*: random / idle tapes from reference spawns; sc_*: scripted crash scenarios (test/cbf);
-    mx_*: mixed traffic (CAVs + IDM/MOBIL HDVs); rw_*: srew / mrew agent rewards."""
-    return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern)) if os.path.basename(f)[:3] in ("ep_", "sc_", "mx_", "rw_", "sl_"))
+    mx_*: mixed traffic (CAVs + IDM/MOBIL HDVs); rw_*: srew / mrew agent rewards; sl_*: with stand-alone
+    safety_layer probes; sv_*: lateral_control = "steer_vel"."""
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern)) if os.path.basename(f)[:3] in ("ep_", "sc_", "mx_", "rw_", "sl_", "sv_"))
 
 
 def load_episode(path):
@@ -37,7 +38,8 @@ def load_episode(path):
 
 def env_kwargs(meta):
     cfg = {"safety_guarantee": meta["shield"], "HEADWAY_TIME": meta["headway_time"],
-           "action_masking": False, "agent_reward": meta.get("agent_reward", "default")}
+           "action_masking": False, "agent_reward": meta.get("agent_reward", "default"),
+           "lateral_control": meta.get("lateral_control", "steer")}
     return dict(env_id=meta["env_id"], config=cfg, cbf_eta=meta["eta"], cbf_tau=meta["headway_time"],
                 obs_f64=True, trace=True, n_hdv=meta.get("n_hdv", 0))
 
@@ -67,6 +69,8 @@ def _force_state(env, z, meta, t, s_at):
         h2 = np.stack([pf[:, SF["x"]], pf[:, SF["speed"]] * np.cos(pf[:, SF["heading"]])])
     else:
         h2 = np.zeros((2, n))
+    if "sub_sa" in z.files:
+        put(env.f64[F["STEER_ANGLE"]], z["sub_sa"][s_at - 1])
     for k, nm in enumerate(("X", "VX")):
         put(env.f64[F["H1_" + nm]], h1[k])
         put(env.f64[F["H2_" + nm]], h2[k])
@@ -171,6 +175,16 @@ def replay(make_env, path, tol=FLOAT_TOL, check_qp=True, teacher_forcing=True, m
                                     abs(tr[k, abi.T["QP_D"], j] - qp_x[q_loc, 0]))
                             step_mx["qp"] = max(step_mx["qp"], float(e))
                             q_loc += 1
+                if "sub_pf" in z.files and is_v1 and shielded:  # control-profile tail: safe_status + min_headway
+                    pf = z["sub_pf"][s_at + k]
+                    ran_ref = pf[:, 0] > 0
+                    st = tr[k, abi.T["STATUS"]]
+                    discrete(np.array_equal(~np.isnan(st), ran_ref), tr, k, (path, t, k, "shield ran", st, pf[:, 0]))
+                    if ran_ref.any():
+                        bits = np.where(ran_ref, np.nan_to_num(st), 0).astype(np.int64)
+                        for b_, col_ in ((abi.ST_IS_OPTIMAL, 1), (abi.ST_IS_SAFE, 2), (abi.ST_IS_INVARIANT, 3)):
+                            discrete(np.array_equal(((bits & b_) != 0)[ran_ref], pf[ran_ref, col_] > 0), tr, k, (path, t, k, "status", col_))
+                        step_mx["state"] = max(step_mx["state"], float(np.abs(tr[k, abi.T["HEADWAY"]][ran_ref] - pf[ran_ref, 4]).max()))
                 for name, col in (("X", "x"), ("Y", "y"), ("HEADING", "heading"), ("SPEED", "speed")):
                     step_mx["state"] = max(step_mx["state"], float(np.abs(tr[k, abi.T[name]] - gf[:, SF[col]]).max()))
                 cols = [("ACT_STEER", "act_steer"), ("ACT_ACC", "act_acc")]
@@ -178,6 +192,9 @@ def replay(make_env, path, tol=FLOAT_TOL, check_qp=True, teacher_forcing=True, m
                     cols += [("SAFE_STEER", "safe_steer"), ("SAFE_ACC", "safe_acc")]
                 for name, col in cols:
                     step_mx["action"] = max(step_mx["action"], float(np.abs(tr[k, abi.T[name]] - gf[:, SF[col]]).max()))
+            if "sub_sa" in z.files and nsub > 0:  # MDPLCVehicle.steering_angle after the step
+                got_sa = env.f64[abi.F["STEER_ANGLE"], 0].cpu().numpy()
+                step_mx["state"] = max(step_mx["state"], float(np.abs(got_sa - z["sub_sa"][s_at + nsub - 1]).max()))
             o = {k2: v[0].cpu().numpy() for k2, v in out.items()}
             step_mx["obs"] = max(step_mx["obs"], float(np.abs(obs[0, :nc].cpu().numpy() - z["obs"][t]).max()))
             step_mx["reward"] = max(step_mx["reward"], abs(float(o["reward"]) - z["reward"][t]),

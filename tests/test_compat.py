@@ -74,14 +74,15 @@ def test_training_seed_increments():
 
 
 @pytest.mark.parametrize("name", ["ep_v0_none_N4_s25", "ep_v1_mass_N8_s0", "ep_v1_hss_N4_s50", "mx_v1_mass_4c3h_s25",
-                                  "mx_v0_none_3c3h_s0"])
+                                  "mx_v0_none_3c3h_s0", "sv_v1_hss_N4_s25"])
 def test_step_tuple_matches_golden(name):
     """The (obs, reward, done, info) tuple of MergeEnv.step through the adapter, free-running."""
     z, meta = load_episode(os.path.join(GOLDEN, name + ".npz"))
     compat.CBFType.GAMMA_B, compat.CBFType.TAU = meta["eta"], meta["headway_time"]
     env = compat.MergeEnvCompat(meta["env_id"], backend_factory=_factory)
     env.config.update({"safety_guarantee": meta["shield"], "HEADWAY_TIME": meta["headway_time"],
-                       "action_masking": False, "traffic_type": "cav", "mixed_traffic": False})
+                       "action_masking": False, "traffic_type": "cav", "mixed_traffic": False,
+                       "lateral_control": meta.get("lateral_control", "steer")})
     env._num_vehicles = lambda num_CAV=0: (meta["n"], meta.get("n_hdv", 0))
     obs, avail = env.reset(is_training=False, testing_seeds=meta["seed"])
     np.testing.assert_allclose(obs, z["obs0"], rtol=0, atol=1e-12)
@@ -99,6 +100,47 @@ def test_step_tuple_matches_golden(name):
     assert done and abs(info["merge_percent"] - z["merge_percent"][meta["steps"] - 1]) <= 1e-9
     assert env.is_crashed() == meta["crashed"]
     assert env.controlled_vehicles[0].lane_index in abi.LANE_INDEX
+
+
+@pytest.mark.parametrize("name", ["sl_v1_mass_3c3h_s50", "sv_v1_mass_N8_s50"])
+def test_control_profile_matches_reference(name):
+    """store_profile: the per-sub-step state_hist / action_hist records (safe_controller.py:187-227,
+    behavior.py:509-521) that MAPPOControlEval.evaluation exports (marl/mappo.py:420-438)."""
+    from golden_util import SF, SI
+    z, meta = load_episode(os.path.join(GOLDEN, name + ".npz"))
+    compat.CBFType.GAMMA_B, compat.CBFType.TAU = meta["eta"], meta["headway_time"]
+    env = compat.MergeEnvCompat(meta["env_id"], backend_factory=_factory, store_profile=True)
+    env.config.update({"safety_guarantee": meta["shield"], "HEADWAY_TIME": meta["headway_time"], "action_masking": False,
+                       "lateral_control": meta.get("lateral_control", "steer")})
+    env._num_vehicles = lambda num_CAV=0: (meta["n"], meta.get("n_hdv", 0))
+    env.reset(is_training=False, testing_seeds=meta["seed"])
+    steps = 30
+    for t in range(steps):
+        env.step(tuple(int(a) for a in z["actions"][t]))
+    cp = env.control_profile()
+    n, n_all = meta["n"], meta["n"] + meta.get("n_hdv", 0)
+    assert sorted(cp) == sorted(["av%d" % j for j in range(n)] + ["hdv%d" % j for j in range(n, n_all)])
+    nsub = int(z["sub_count"][:steps].sum())
+    for j in range(n_all):
+        rec = cp[("av%d" if j < n else "hdv%d") % j]
+        assert len(rec["state_hist"]) == len(rec["action_hist"]) == nsub
+        for k in (0, 1, 2, 7, nsub - 1):
+            gf, pf = z["sub_f"][k][j], z["sub_pf"][k][j]
+            st, ac = rec["state_hist"][k], rec["action_hist"][k]
+            assert abs(st["x"] - gf[SF["x"]]) <= 1e-9 and abs(st["speed"] - gf[SF["speed"]]) <= 1e-9
+            assert abs(st["t_step"] - (k + 1) / 15) <= 1e-9 and abs(ac["t_step"] - st["t_step"]) == 0
+            assert abs(ac["steering"] - gf[SF["safe_steer" if j < n else "act_steer"]]) <= 1e-9
+            if j < n:
+                assert abs(ac["acceleration"] - gf[SF["safe_acc"]]) <= 1e-9
+                assert abs(ac["ull_acceleration"] - gf[SF["act_acc"]]) <= 1e-9
+                assert ("safe_status" in st) == bool(pf[0]) == ("safe_diff" in ac)
+                assert abs(st["headway"] - pf[4]) <= 1e-9
+                if pf[0]:
+                    assert (st["safe_status"]["is_optimal"], st["safe_status"]["is_safe"], st["safe_status"]["is_invariant"]) == \
+                        (bool(pf[1]), bool(pf[2]), bool(pf[3]))
+                if "sub_sa" in z.files:
+                    assert abs(st["steering_angle"] - z["sub_sa"][k][j]) <= 1e-9
+                assert ac["lc_action"] == int(z["sub_i"][k][j][SI["hl_action"]])
 
 
 def test_error_behaviour():

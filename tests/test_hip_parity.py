@@ -110,6 +110,10 @@ CASES = [
     # alternate agent rewards -- 9th field
     ("merge-multi-agent-v1", "cbf-cav", 8, 256, 110, 0.03125, 0.5, 0, "mrew"),
     ("merge-multi-agent-v1", "cbf-avs_cint", 6, 256, 110, 0.03125, 0.5, 2, "srew"),
+    # lateral_control = "steer_vel" -- 10th field
+    ("merge-multi-agent-v1", "cbf-cav", 8, 256, 110, 0.03125, 0.5, 0, "default", "steer_vel"),
+    ("merge-multi-agent-v1", "cbf-avs_cint", 7, 256, 110, 0.03125, 0.5, 3, "default", "steer_vel"),
+    ("merge-multi-agent-v1", "none", 4, 256, 60, 0.0, 0.5, 0, "default", "steer_vel"),
 ]
 
 
@@ -119,7 +123,9 @@ def test_random_rollout_vs_oracle(case):
     env_id, safety, N, E, steps, eta, tau = case[:7]
     n_hdv = case[7] if len(case) > 7 else 0
     agent_reward = case[8] if len(case) > 8 else "default"
-    kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau, "agent_reward": agent_reward},
+    lateral = case[9] if len(case) > 9 else "steer"
+    kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau, "agent_reward": agent_reward,
+                                     "lateral_control": lateral},
               cbf_eta=eta, cbf_tau=tau,
               obs_f64=True, seed=1000, auto_reset=True, n_hdv=n_hdv)
     gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)

@@ -35,13 +35,14 @@ from highway_env.vehicle.safety.cbf import CBFType  # noqa: E402
 from highway_env.vehicle.controller import MDPVehicle  # noqa: E402
 from highway_env.vehicle.safe_controller import MDPLCVehicle  # noqa: E402
 
-OUT = os.path.join(REPO, "tests", "golden")
+OUT = os.environ.get("MM_GOLDEN_OUT", os.path.join(REPO, "tests", "golden"))
 LANE_ID = {("a", "b", 0): 0, ("b", "c", 0): 1, ("b", "c", 1): 2,
            ("c", "d", 0): 3, ("j", "k", 0): 4, ("k", "b", 0): 5}
 LANE_IX = {v: k for k, v in LANE_ID.items()}
 HL = {None: -1, "LANE_LEFT": 0, "IDLE": 1, "LANE_RIGHT": 2, "FASTER": 3, "SLOWER": 4}
 
 _SUBSTEP_LOG = None
+ONLY = []  # tape-name prefixes to (re)generate; empty = everything
 _orig_road_step = Road.step
 
 
@@ -64,18 +65,32 @@ def _veh_snapshot(v):
     return f, i
 
 
+def _profile_tail(v):
+    """What log_step (safe_controller.py:187-227) just appended to the vehicle's control profile:
+    [shield ran, is_optimal, is_safe, is_invariant, headway]."""
+    if not isinstance(v, MDPLCVehicle) or not v.state_hist:
+        return [0, 0, 0, 0, np.nan]
+    rec = v.state_hist[-1]
+    st = rec.get("safe_status")
+    if st is None:
+        return [0, 0, 0, 0, float(rec["headway"])]
+    return [1, float(bool(st["is_optimal"])), float(bool(st["is_safe"])), float(bool(st["is_invariant"])), float(rec["headway"])]
+
+
 def _road_step_logged(self, dt):
     _orig_road_step(self, dt)
     if _SUBSTEP_LOG is not None:
         rows = [_veh_snapshot(v) for v in self.vehicles]
         _SUBSTEP_LOG.append((np.array([r[0] for r in rows], dtype=np.float64),
-                             np.array([r[1] for r in rows], dtype=np.int32)))
+                             np.array([r[1] for r in rows], dtype=np.int32),
+                             np.array([float(getattr(v, "steering_angle", 0.0)) for v in self.vehicles]),
+                             np.array([_profile_tail(v) for v in self.vehicles])))
 
 
 Road.step = _road_step_logged
 
 
-def make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=0, agent_reward="default"):
+def make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=0, agent_reward="default", lateral_control="steer"):
     """Mirror of how run_mappo.py:137-171 configures an env (values from the cited .ini files)."""
     CBFType.GAMMA_B = eta
     CBFType.TAU = headway_time
@@ -91,7 +106,7 @@ def make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=0, agent_reward="de
     env.config["traffic_density"] = 1
     env.config["action_masking"] = False
     env.config["safety_guarantee"] = shield
-    env.config["lateral_control"] = "steer"
+    env.config["lateral_control"] = lateral_control
     env.config["mixed_traffic"] = n_hdv > 0
     env.config["traffic_type"] = "mixed" if n_hdv > 0 else "cav"
     env.config["agent_reward"] = agent_reward
@@ -140,9 +155,13 @@ def _probe_safety_layer(env, shield, t, rng):
 
 
 def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta, p=None,
-                max_steps=100, scripted=None, placement=None, n_hdv=0, agent_reward="default", probe_shield=False):
+                max_steps=100, scripted=None, placement=None, n_hdv=0, agent_reward="default", probe_shield=False,
+                lateral_control="steer"):
     global _SUBSTEP_LOG
-    env = make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=n_hdv, agent_reward=agent_reward)
+    if ONLY and not any(name.startswith(o) for o in ONLY):
+        return None
+    env = make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=n_hdv, agent_reward=agent_reward,
+                   lateral_control=lateral_control)
     obs0, mask0 = env.reset(is_training=False, testing_seeds=seed)
     if placement is not None:
         obs0 = _place_vehicles(env, placement)
@@ -152,7 +171,7 @@ def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta,
     rng = np.random.RandomState(tape_seed)
     p = p or [0.1, 0.6, 0.1, 0.1, 0.1]
     cvxopt.solvers.log = []
-    sub_f, sub_i, sub_count = [], [], []
+    sub_f, sub_i, sub_sa, sub_pf, sub_count = [], [], [], [], []
     rec = {k: [] for k in ("actions", "obs", "reward", "done", "agents_rewards", "regional_rewards",
                            "agents_dones", "average_speed", "traffic_speed", "min_headway",
                            "merge_percent", "action_mask", "qp_count")}
@@ -170,9 +189,11 @@ def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta,
         nqp0 = len(cvxopt.solvers.log)
         obs, reward, done, info = env.step(a)
         sub_count.append(len(_SUBSTEP_LOG))
-        for f, i in _SUBSTEP_LOG:
+        for f, i, sa, pf in _SUBSTEP_LOG:
             sub_f.append(f)
             sub_i.append(i)
+            sub_sa.append(sa)
+            sub_pf.append(pf)
         _SUBSTEP_LOG = None
         rec["actions"].append(a)
         rec["obs"].append(np.asarray(obs, dtype=np.float64))
@@ -198,7 +219,8 @@ def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta,
         qp_G[k, :g.shape[0]] = g
         qp_h[k, :h.shape[0]] = h
         qp_x[k] = x
-    meta = dict(env_id=env_id, shield=shield, n=n_cav, n_hdv=n_hdv, agent_reward=agent_reward, seed=seed, tape_seed=tape_seed,
+    meta = dict(name=name, env_id=env_id, shield=shield, n=n_cav, n_hdv=n_hdv, agent_reward=agent_reward,
+                lateral_control=lateral_control, seed=seed, tape_seed=tape_seed,
                 headway_time=headway_time, eta=eta, n_merge=int(env.n_merge),
                 n_s=int(env.n_s), crashed=bool(env.is_crashed()), steps=t,
                 qp_solver="exact-KKT closed form (cvxopt 1.2.7 unavailable)")
@@ -218,10 +240,14 @@ def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta,
         min_headway=np.array(rec["min_headway"]), merge_percent=np.array(rec["merge_percent"]),
         action_mask=np.array(rec["action_mask"]), qp_count=np.array(rec["qp_count"], dtype=np.int32),
         qp_rows=qp_rows, qp_G=qp_G, qp_h=qp_h, qp_x=qp_x,
+        # MDPLCVehicle.steering_angle after every sub-step (non-zero only under lateral_control="steer_vel")
+        **({"sub_sa": np.array(sub_sa)} if lateral_control != "steer" else {}),
+        # control-profile tail per sub-step: [shield ran, is_optimal, is_safe, is_invariant, headway]
+        sub_pf=np.array(sub_pf),
         sl_t=np.array([p_[0] for p_ in probes], dtype=np.int32),
-        sl_act=np.array([p_[1] for p_ in probes], dtype=np.float64).reshape(len(probes), -1, 2),
-        sl_safe=np.array([p_[2] for p_ in probes], dtype=np.float64).reshape(len(probes), -1, 2),
-        sl_status=np.array([p_[3] for p_ in probes], dtype=np.float64).reshape(len(probes), -1, 6))
+        sl_act=np.array([p_[1] for p_ in probes], dtype=np.float64).reshape(len(probes), n_cav, 2),
+        sl_safe=np.array([p_[2] for p_ in probes], dtype=np.float64).reshape(len(probes), n_cav, 2),
+        sl_status=np.array([p_[3] for p_ in probes], dtype=np.float64).reshape(len(probes), n_cav, 6))
     print("%-40s steps=%3d crashed=%d qps=%d" % (name, t, meta["crashed"], len(qps)))
     return meta
 
@@ -371,8 +397,9 @@ def gen_reset():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    gen_units()
-    gen_reset()
+    if not ONLY:
+        gen_units()
+        gen_reset()
     metas = []
     v0, v1 = "merge-multi-agent-v0", "merge-multi-agent-v1"
     # (1) unshielded, reference arithmetic end to end (configs_marl-cav-unsafe.ini: tau 1.2)
@@ -431,11 +458,29 @@ def main():
     metas.append(run_episode("rw_v1_hss_srew_N4_s0", v1, "cbf-avs_cint", 4, 0, 77, 0.5, 0.03125, p=lc2, agent_reward="srew"))
     metas.append(run_episode("rw_v1_mass_mrew_N8_s25", v1, "cbf-cav", 8, 25, 78, 0.5, 0.03125, p=lc2, agent_reward="mrew"))
     metas.append(run_episode("rw_v1_mass_mrew_3c3h_s50", v1, "cbf-cav", 3, 50, 79, 0.5, 0.03125, p=lc2, n_hdv=3, agent_reward="mrew"))
+    # (6) stand-alone safety_layer(...) probes: the reference function called per vehicle on deep copies
+    metas.append(run_episode("sl_v1_hss_N4_s0", v1, "cbf-avs_cint", 4, 0, 91, 0.5, 0.03125, p=lc2, probe_shield=True))
+    metas.append(run_episode("sl_v1_mass_N8_s25", v1, "cbf-cav", 8, 25, 92, 0.5, 0.03125, p=lc2, probe_shield=True))
+    metas.append(run_episode("sl_v1_mass_3c3h_s50", v1, "cbf-cav", 3, 50, 93, 0.5, 0.03125, p=lc2, n_hdv=3, probe_shield=True))
+    # (7) lateral_control = "steer_vel" (safe_controller.py:84-98,124-150): steering-velocity command, steering-angle state
+    metas.append(run_episode("sv_v1_none_N4_s0", v1, "none", 4, 0, 61, 0.5, 0.0, p=lc2, lateral_control="steer_vel"))
+    metas.append(run_episode("sv_v1_hss_N4_s25", v1, "cbf-avs_cint", 4, 25, 62, 0.5, 0.03125, p=lc2, lateral_control="steer_vel"))
+    metas.append(run_episode("sv_v1_mass_N8_s50", v1, "cbf-cav", 8, 50, 63, 0.5, 0.03125, p=lc2, lateral_control="steer_vel"))
+    metas.append(run_episode("sv_v1_mass_3c3h_s75", v1, "cbf-cav", 3, 75, 64, 0.5, 0.03125, p=lc2, n_hdv=3, lateral_control="steer_vel"))
+    # the index is rebuilt from the tapes on disk, so a partial regeneration (`only <prefix> ...`) keeps the rest
+    import glob
+    metas = []
+    for f in sorted(glob.glob(os.path.join(OUT, "*_*.npz"))):
+        m = json.loads(str(np.load(f)["meta"]))
+        m["name"] = os.path.basename(f)[:-4]
+        metas.append(m)
     with open(os.path.join(OUT, "index.json"), "w") as fh:
         json.dump(metas, fh, indent=1)
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "only":  # e.g. `gen_golden.py only sv_ sl_`: regenerate just those tapes
+        ONLY = sys.argv[2:]
     if len(sys.argv) > 1 and sys.argv[1] == "reset":
         os.makedirs(OUT, exist_ok=True)
         gen_reset()

@@ -1,4 +1,4 @@
-"""Diagnostic: per-phase cycle shares of step_kernel (build with -DMM_STAMPS -DMM_ONLY_G=8)."""
+"""Diagnostic: per-phase cycle shares of step_kernel (build with `make tuning EXTRA="-DMM_STAMPS -DMM_ONLY_G=8 -DMM_ONLY_MIXED=false"`, copy to libmm_hip_stamps.so)."""
 import ctypes, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
