@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--shield", choices=sorted(SHIELDS), default="mass")
     ap.add_argument("--env-id", default="merge-multi-agent-v1")
     ap.add_argument("--obs-f64", action="store_true")
+    ap.add_argument("--hdv", type=int, default=0, help="mixed traffic: the last HDV of the --agents vehicles are IDM/MOBIL HDVs (not the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=32768)
     ap.add_argument("--cpu-steps", type=int, default=400)
@@ -84,7 +85,7 @@ def main():
     E, N = args.envs, args.agents
     cfg = {"safety_guarantee": SHIELDS[args.shield], "HEADWAY_TIME": 0.5 if args.shield != "none" else 1.2}
     kw = dict(cbf_eta=0.03125 if args.shield != "none" else 0.0, cbf_tau=cfg["HEADWAY_TIME"], seed=1000,
-              auto_reset=True, obs_f64=args.obs_f64)
+              auto_reset=True, obs_f64=args.obs_f64, n_hdv=args.hdv)
     env = VecMergeEnv(E, N, env_id=args.env_id, config=cfg, device=dev, first_env=rank * E, **kw)
     metrics = env.enable_metrics()
     env.reset()
@@ -149,14 +150,15 @@ def main():
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass
         line = {
-            "metric": "agent-steps/sec (whole node), MASS CBF shield on, 65536 envs x 8 CAVs" if args.shield == "mass"
+            "metric": "agent-steps/sec (whole node), MASS CBF shield on, 65536 envs x 8 CAVs" if (args.shield == "mass" and not args.hdv)
                       else "agent-steps/sec (whole node), shield=%s" % args.shield,
             "value": agent_steps / elapsed, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d envs x %d CAVs per GPU, %s, safety_guarantee=%s, eta=0.03125, tau=%.1f, "
-                                   "100-step episodes with auto-reset, categorical action tape"
-                                   % (E, N, args.env_id, cfg["safety_guarantee"], cfg["HEADWAY_TIME"]),
+                                   "100-step episodes with auto-reset, categorical action tape%s"
+                                   % (E, N, args.env_id, cfg["safety_guarantee"], cfg["HEADWAY_TIME"],
+                                      (", of which %d HDVs per env" % args.hdv) if args.hdv else ""),
                        "envs_per_gpu": E, "agents": N, "obs_dtype": "f64" if args.obs_f64 else "f32",
                        "parallelism": "env-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -9,6 +9,12 @@ actor runs as batched GEMMs (rocBLAS/hipBLASLt through torch -- plain library GE
 they are), sampling is `torch.multinomial`, and the discounting is a reversed scan over the
 rollout with episode boundaries taken from `done`.
 
+The loop is launch-bound once `mm_step` takes < 0.5 ms (about a dozen small launches per policy
+step), so `use_graph=True` captures the WHOLE rollout -- T x (policy forward, sample, mm_step,
+bookkeeping) + bootstrap + discounting -- into one hipGraph on first use and replays it afterwards
+(static output buffers; the env state, the carried observation and the RNG offset advance inside
+the graph exactly as they do eagerly).
+
 Networks mirror marl/single_agent/Model_common.py:5-41 (state -> 128 -> 128 -> n_a, log-softmax;
 critic takes the one-hot action after the first layer).
 """
@@ -67,7 +73,7 @@ class DeviceRollout(object):
     """MAPPO.interact for a whole env batch; see the module docstring."""
 
     def __init__(self, env, actor, critic=None, roll_out_n_steps=100, reward_gamma=0.99, reward_scale=20.0,
-                 reward_type="regionalR", generator=None):
+                 reward_type="regionalR", generator=None, use_graph=False):
         assert reward_type in ("regionalR", "global_R")  # marl/mappo.py:39
         self.env, self.actor, self.critic = env, actor, critic
         self.T, self.gamma, self.reward_scale, self.reward_type = roll_out_n_steps, reward_gamma, reward_scale, reward_type
@@ -75,19 +81,56 @@ class DeviceRollout(object):
         self.n_a = env.n_a
         self.obs, _ = env.reset()
         self.obs = self.obs.clone()
+        self.use_graph = bool(use_graph)
+        if self.use_graph:
+            if self.obs.device.type != "cuda":
+                raise RuntimeError("use_graph needs the device backend (hipGraph capture)")
+            if generator is not None:
+                raise ValueError("use_graph samples from the default CUDA generator (captured Philox offset)")
+        self._graph, self._static = None, None
 
     @torch.no_grad()
     def act(self, obs):
         """exploration_action / action (marl/mappo.py:220-236): sample from softmax(actor(obs))."""
         E, N, S = obs.shape
         logp = self.actor(obs.reshape(E * N, S).float())
-        return torch.multinomial(logp.exp(), 1, generator=self.generator).view(E, N).to(torch.int32)
+        # np.random.choice(n_a, p=softmax) (marl/mappo.py:229) is inverse-CDF sampling: cdf.searchsorted(u, "right").
+        # Same here, with a device uniform (also keeps the op list free of torch.multinomial's device-side
+        # asserts, which do not survive hipGraph replay).
+        cdf = logp.exp().double().cumsum(-1)
+        cdf = cdf / cdf[:, -1:]
+        u = torch.rand(E * N, 1, dtype=torch.float64, device=obs.device, generator=self.generator)
+        return (cdf <= u).sum(-1).clamp_(max=self.n_a - 1).view(E, N).to(torch.int32)
 
     @torch.no_grad()
     def interact(self):
         """One rollout of `roll_out_n_steps` policy steps on every env (auto-reset on).
         Returns states [T,E,N,S], actions [T,E,N], discounted returns [T,E,N], dones [T,E] and the
-        per-step info means the reference logs (average speed, min headway)."""
+        per-step info means the reference logs (average speed, min headway).  With `use_graph` the
+        returned tensors are the graph's static buffers: consume them before the next call."""
+        if not self.use_graph:
+            return self._interact()
+        if self._graph is None:
+            dev = self.obs.device
+            self._carry = self.obs  # static input/output of the graph: the observation carried between rollouts
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):  # warm-up outside capture (lazy library init, allocator)
+                self._interact()
+                self._carry.copy_(self.obs)
+                self.obs = self._carry
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._static = self._interact()
+                self._carry.copy_(self.obs)
+            self.obs = self._carry
+        self._graph.replay()
+        return self._static
+
+    @torch.no_grad()
+    def _interact(self):
         env, T = self.env, self.T
         E, N, S = self.obs.shape
         dev = self.obs.device
@@ -112,7 +155,8 @@ class DeviceRollout(object):
         final_value = torch.zeros(E, N, dtype=torch.float64, device=dev)
         if self.critic is not None:
             fa = self.act(obs)
-            one_hot = torch.nn.functional.one_hot(fa.long(), self.n_a).float()
+            # (not F.one_hot: its device-side range asserts do not survive hipGraph capture)
+            one_hot = (fa.unsqueeze(-1) == torch.arange(self.n_a, device=dev, dtype=fa.dtype)).float()
             val = self.critic(obs.reshape(E * N, S).float(), one_hot.view(E * N, self.n_a)).view(E, N).double()
             final_value = torch.where(dones[-1].bool().unsqueeze(-1), final_value, val)
         if self.reward_scale > 0:

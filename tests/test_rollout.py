@@ -66,3 +66,36 @@ def test_interact_on_gpu():
     out = ro.interact()
     assert out["returns"].is_cuda and torch.isfinite(out["returns"]).all()
     assert out["states"].shape == (20, E, N, 30)
+
+
+@pytest.mark.gpu
+def test_graph_captured_rollout_equals_eager():
+    """use_graph: the whole rollout replayed as one hipGraph gives the same tensors as the eager loop
+    (a greedy policy makes the comparison independent of the RNG stream), twice in a row."""
+    import time
+    from marl_mass_amd import VecMergeEnv
+    E, N, T = 8192, 8, 25
+    kw = dict(config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5, seed=9, auto_reset=True)
+    torch.manual_seed(3)
+
+    class GreedyActor(ActorNetwork):  # exactly one-hot log-probabilities: sampling has a single outcome
+        def forward(self, state):
+            lp = super().forward(state)
+            return torch.where(lp == lp.max(-1, keepdim=True).values, 0.0, -float("inf")).to(lp.dtype)
+
+    actor = GreedyActor(30, 128, 5).cuda()
+    critic = CriticNetwork(30, 5, 128).cuda()
+    eager = DeviceRollout(VecMergeEnv(E, N, **kw), actor, critic, roll_out_n_steps=T)
+    graph = DeviceRollout(VecMergeEnv(E, N, **kw), actor, critic, roll_out_n_steps=T, use_graph=True)
+    graph.interact()  # warm-up + capture + first replay = 2 rollouts
+    eager.interact()
+    eager.interact()
+    for _ in range(2):
+        a, b = eager.interact(), graph.interact()
+        torch.cuda.synchronize()
+        for k in ("states", "actions", "returns", "dones", "average_speed", "min_headway"):
+            assert torch.equal(a[k], b[k]), k
+    assert torch.equal(eager.env.f64.nan_to_num(), graph.env.f64.nan_to_num())
+    t0 = time.perf_counter(); eager.interact(); torch.cuda.synchronize(); t1 = time.perf_counter()
+    graph.interact(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print("rollout of %d steps x %d envs: eager %.2f ms, hipGraph %.2f ms" % (T, E, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
