@@ -172,7 +172,7 @@ def main():
         }
         if valu is not None:
             line["roofline_secondary"] = valu
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(args, args.env_id, cfg, kw)
         print(json.dumps(line))
     if world > 1:

@@ -101,6 +101,11 @@ CASES = [
     ("merge-multi-agent-v1", "cbf-cav", 5, 128, 60, 0.03125, 0.5),   # ragged group (N < G)
     ("merge-multi-agent-v1", "cbf-cav", 11, 128, 60, 0.03125, 0.5),  # G = 16
     ("merge-multi-agent-v1", "cbf-avs_cint", 2, 128, 60, 0.5, 1.2),
+    ("merge-multi-agent-v1", "cbf-cav", 3, 128, 60, 0.03125, 0.5),        # ragged G = 4
+    ("merge-multi-agent-v1", "cbf-avs_cint", 7, 128, 110, 0.03125, 0.5),  # ragged G = 8
+    ("merge-multi-agent-v1", "cbf-cav", 12, 64, 110, 0.03125, 0.5),       # the 6 + 6 spawn-slot maximum
+    ("merge-multi-agent-v1", "cbf-avs_cint", 9, 64, 60, 0.03125, 0.5),    # G = 16, HSS
+    ("merge-multi-agent-v0", "none", 12, 64, 40, 0.0, 1.2),
     # mixed traffic: (N total vehicles, of which n_hdv IDM/MOBIL HDVs) -- 8th field
     ("merge-multi-agent-v0", "none", 6, 256, 60, 0.0, 1.2, 3),
     ("merge-multi-agent-v1", "none", 8, 256, 60, 0.0, 0.5, 4),
