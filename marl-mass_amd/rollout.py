@@ -21,6 +21,8 @@ critic takes the one-hot action after the first layer).
 import torch
 from torch import nn
 
+from . import _cabi as abi
+
 
 class ActorNetwork(nn.Module):
     """Model_common.py:5-22."""
@@ -164,3 +166,61 @@ class DeviceRollout(object):
         returns = discount_rewards(rewards, dones, final_value, self.gamma)
         return {"states": states, "actions": actions, "returns": returns, "dones": dones,
                 "average_speed": speed_sum / T, "min_headway": min_headway}
+
+    @torch.no_grad()
+    def evaluate(self, seeds=None):
+        """MAPPO.evaluation (marl/mappo.py:255-361) for a whole batch: every env slot runs ONE evaluation
+        episode (its own seed, `env.reset(is_training=False, testing_seeds=seed)` in the reference) to its
+        terminal step while the others keep stepping; per-episode results are taken at each env's own end.
+
+        Returns (rewards [T_max, E] with NaN after an episode's end, (vehicle_speed, vehicle_position)
+        [T_max, E, N] likewise, ext_info) where ext_info has the reference's keys: steps, avg_speeds,
+        crash_count, min_headway (one number, min over all steps of all episodes), traffic_speeds,
+        merge_percents -- per env as tensors."""
+        env = self.env
+        E, N, dev = env.E, env.N, self.obs.device
+        was_auto = env.auto_reset
+        env.configure(auto_reset=False)
+        try:
+            # an evaluation episode is a function of its seed alone (the reference re-seeds the global RNG):
+            # restart the per-slot episode counter that the device RNG mixes in
+            env.env_i32[abi.EP["EPISODE"]].zero_()
+            obs, _ = env.reset(seeds=None if seeds is None else torch.as_tensor(seeds, dtype=torch.int64))
+            T = env.T
+            nan = float("nan")
+            rewards = torch.full((T, E), nan, dtype=torch.float64, device=dev)
+            vspeed = torch.full((T, E, N), nan, dtype=torch.float64, device=dev)
+            vpos = torch.full((T, E, N), nan, dtype=torch.float64, device=dev)
+            alive = torch.ones(E, dtype=torch.bool, device=dev)
+            steps = torch.zeros(E, dtype=torch.int32, device=dev)
+            speed_sum = torch.zeros(E, dtype=torch.float64, device=dev)
+            tspeed_sum = torch.zeros(E, dtype=torch.float64, device=dev)
+            crash = torch.zeros(E, dtype=torch.bool, device=dev)
+            merge = torch.full((E,), nan, dtype=torch.float64, device=dev)
+            min_headway = torch.full((), float("inf"), dtype=torch.float64, device=dev)
+            for t in range(T):
+                a = self.act(obs)
+                obs, reward, done, info = env.step(a)
+                rewards[t] = torch.where(alive, reward, rewards[t])
+                vspeed[t] = torch.where(alive[:, None], info["agents_info"][..., 2], vspeed[t])
+                vpos[t] = torch.where(alive[:, None], info["agents_info"][..., 0], vpos[t])
+                steps += alive.int()
+                speed_sum += torch.where(alive, info["average_speed"], torch.zeros_like(speed_sum))
+                tspeed_sum += torch.where(alive, info["traffic_speed"], torch.zeros_like(tspeed_sum))
+                mh = torch.where(alive, info["min_headway"], torch.full_like(info["min_headway"], float("inf")))
+                min_headway = torch.minimum(min_headway, mh.min())
+                ending = alive & done.bool()
+                crash |= ending & info["crashed"].bool().any(-1)  # env.is_crashed() at the episode's end
+                merge = torch.where(ending, info["merge_percent"], merge)
+                alive = alive & ~done.bool()
+                if not bool(alive.any()):  # one host sync per policy step; evaluation is not the hot loop
+                    break
+            n = steps.clamp(min=1).double()
+            ext_info = {"steps": steps, "avg_speeds": speed_sum / n, "crash_count": crash, "min_headway": float(min_headway),
+                        "traffic_speeds": tspeed_sum / n, "merge_percents": merge}
+            tmax = int(steps.max())
+            return rewards[:tmax], (vspeed[:tmax], vpos[:tmax]), ext_info
+        finally:
+            env.configure(auto_reset=was_auto)
+            self.obs, _ = env.reset()
+            self.obs = self.obs.clone()

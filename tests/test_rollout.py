@@ -99,3 +99,42 @@ def test_graph_captured_rollout_equals_eager():
     t0 = time.perf_counter(); eager.interact(); torch.cuda.synchronize(); t1 = time.perf_counter()
     graph.interact(); torch.cuda.synchronize(); t2 = time.perf_counter()
     print("rollout of %d steps x %d envs: eager %.2f ms, hipGraph %.2f ms" % (T, E, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
+
+
+def test_evaluate_matches_per_episode_loop():
+    """DeviceRollout.evaluate vs the reference's evaluation loop (marl/mappo.py:255-361) run env by env
+    on single-env batches with the same seeds and a greedy policy."""
+    torch.manual_seed(0)
+    E, N = 5, 4
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "none", "HEADWAY_TIME": 1.2}, seed=40)
+
+    class GreedyActor(ActorNetwork):
+        def forward(self, state):
+            lp = super().forward(state)
+            return torch.where(lp == lp.max(-1, keepdim=True).values, 0.0, -float("inf")).to(lp.dtype)
+
+    actor = GreedyActor(30, 128, 5)
+    ro = DeviceRollout(oracle_env.OracleEnv(E, N, auto_reset=True, **kw), actor, roll_out_n_steps=10)
+    seeds = [7, 8, 9, 10, 11]
+    rewards, (vs, vp), ext = ro.evaluate(seeds=seeds)
+    assert ro.env.auto_reset is True  # restored
+    for e, sd in enumerate(seeds):  # the reference's loop, one env at a time
+        env1 = oracle_env.OracleEnv(1, N, auto_reset=False, **kw)
+        obs, _ = env1.reset(seeds=torch.tensor([sd]))
+        step, avg, tsp, rs, mh, done = 0, 0.0, 0.0, [], float("inf"), False
+        while not done:
+            lp = actor(obs.reshape(N, 30).float())
+            obs, r, d, info = env1.step(lp.argmax(-1).view(1, N).int())
+            step += 1
+            avg += float(info["average_speed"][0]); tsp += float(info["traffic_speed"][0])
+            mh = min(mh, float(info["min_headway"][0]))
+            rs.append(float(r[0]))
+            done = bool(d[0])
+        assert int(ext["steps"][e]) == step
+        np.testing.assert_allclose(rewards[:step, e].numpy(), np.array(rs), rtol=0, atol=0)
+        assert torch.isnan(rewards[step:, e]).all()
+        assert abs(float(ext["avg_speeds"][e]) - avg / step) <= 1e-12
+        assert abs(float(ext["traffic_speeds"][e]) - tsp / step) <= 1e-12
+        assert bool(ext["crash_count"][e]) == bool(info["crashed"][0].any())
+        assert abs(float(ext["merge_percents"][e]) - float(info["merge_percent"][0])) <= 1e-12
+        assert ext["min_headway"] <= mh + 1e-15
