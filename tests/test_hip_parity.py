@@ -256,6 +256,32 @@ def test_full_size_bit_exact_vs_oracle():
     assert int(gpu.env_i32[abi.EP["EPISODE"]].max()) >= 2, "some envs must have auto-reset"
 
 
+@pytest.mark.parametrize("safety,n_hdv,lateral", [("cbf-cav", 0, "steer"), ("cbf-avs_cint", 0, "steer"), ("cbf-cav", 3, "steer"),
+                                                    ("cbf-cav", 0, "steer_vel")])
+def test_soak_three_episodes_bit_exact(safety, n_hdv, lateral):
+    """Long free-running soak: 4096 envs x 8 vehicles x 320 steps (three full episodes with auto-reset),
+    checked against the oracle every 40 steps and at the end -- 10 M agent-steps per case, every bit."""
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5, "lateral_control": lateral},
+              cbf_eta=0.03125, cbf_tau=0.5, seed=77, auto_reset=True, n_hdv=n_hdv)
+    E, N = 4096, 8
+    oracle_env.library().lib.orc_set_threads(16)
+    gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
+    gpu.reset()
+    cpu.reset()
+    g = torch.Generator().manual_seed(21)
+    p = torch.tensor([0.15, 0.5, 0.15, 0.1, 0.1])
+    for t in range(320):
+        a = torch.multinomial(p, E * N, True, generator=g).view(E, N).int()
+        og, rg, dg, ig = gpu.step(a.cuda())
+        oc, rc, dc, ic = cpu.step(a)
+        if t % 40 == 39 or t == 319:
+            assert torch.equal(gpu.u8.cpu(), cpu.u8) and torch.equal(gpu.env_i32.cpu(), cpu.env_i32), t
+            assert torch.equal(gpu.f64.cpu().nan_to_num(), cpu.f64.nan_to_num()), t
+            assert torch.equal(og.cpu(), oc) and torch.equal(rg.cpu(), rc) and torch.equal(dg.cpu(), dc), t
+            assert torch.equal(ig["regional_rewards"].cpu(), ic["regional_rewards"]), t
+    assert int(gpu.env_i32[abi.EP["EPISODE"]].min()) >= 3
+
+
 def test_full_size_properties():
     """BASELINE c4/c5-sized batch (65536 envs x 8, MASS): size-independent invariants.
     With the shield on and eta=0.03125, tau=0.5 the reference never crashes under the random tape
