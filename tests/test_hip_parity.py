@@ -256,14 +256,16 @@ def test_full_size_bit_exact_vs_oracle():
     assert int(gpu.env_i32[abi.EP["EPISODE"]].max()) >= 2, "some envs must have auto-reset"
 
 
-@pytest.mark.parametrize("safety,n_hdv,lateral", [("cbf-cav", 0, "steer"), ("cbf-avs_cint", 0, "steer"), ("cbf-cav", 3, "steer"),
-                                                    ("cbf-cav", 0, "steer_vel")])
-def test_soak_three_episodes_bit_exact(safety, n_hdv, lateral):
-    """Long free-running soak: 4096 envs x 8 vehicles x 320 steps (three full episodes with auto-reset),
-    checked against the oracle every 40 steps and at the end -- 10 M agent-steps per case, every bit."""
+@pytest.mark.parametrize("safety,n_hdv,lateral,N", [("cbf-cav", 0, "steer", 8), ("cbf-avs_cint", 0, "steer", 8), ("cbf-cav", 3, "steer", 8),
+                                                      ("cbf-cav", 0, "steer_vel", 8), ("cbf-cav", 0, "steer", 4), ("cbf-cav", 0, "steer", 12),
+                                                      ("cbf-avs_cint", 0, "steer", 2), ("cbf-cav", 5, "steer", 11), ("none", 2, "steer", 4)])
+def test_soak_three_episodes_bit_exact(safety, n_hdv, lateral, N):
+    """Long free-running soak: 4096 envs x N vehicles x 320 steps (three full episodes with auto-reset),
+    checked against the oracle every 40 steps and at the end -- ~10 M agent-steps per case, every bit,
+    for every group size (G = 2, 4, 8, 16) and both kernel families (CAV-only / general)."""
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5, "lateral_control": lateral},
               cbf_eta=0.03125, cbf_tau=0.5, seed=77, auto_reset=True, n_hdv=n_hdv)
-    E, N = 4096, 8
+    E = 4096
     oracle_env.library().lib.orc_set_threads(16)
     gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
     gpu.reset()
