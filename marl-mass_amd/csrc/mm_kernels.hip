@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
   int steps = 0, time = 0, n_merge = 0, episode = 0;
   if (e < st.E) {
     steps = st.I[MM_E_STEPS * st.E + e]; time = st.I[MM_E_TIME * st.E + e];
-    n_merge = st.I[MM_E_N_MERGE * st.E + e]; episode = st.I[MM_E_EPISODE * st.E + e];
+    // n_merge / episode are only needed by the epilogue: loaded there, not held across the sub-steps
   }
   if (!MIXED && v.kind == 2) v.kind = 1;  // CAV-only kernels: the host guarantees there are no HDVs
   const bool hdv = MIXED && v.kind == 2;
@@ -1341,6 +1341,7 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
     th = h2d / (vx > 1 ? vx : 1);
   }
   const double min_headway = group_min_d<G>(th);
+  if (e < st.E) { n_merge = st.I[MM_E_N_MERGE * st.E + e]; episode = st.I[MM_E_EPISODE * st.E + e]; }
   double merge_pct = __builtin_nan("");
   if (done) {
     const int n_rem = __popc(group_ballot<G>(
