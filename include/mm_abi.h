@@ -280,6 +280,31 @@ int32_t mm_set_metrics_buffer(MMHandle h, double *metrics);
 const char *mm_last_error(MMHandle h);
 
 /*
+ * Policy head of the rollout loop: exploration_action / action (marl/mappo.py:220-236) for a batch,
+ *   softmax_action = exp(actor(state));  action = np.random.choice(n_a, p=softmax_action)
+ * np.random.choice is inverse-CDF sampling: cdf = cumsum(p); cdf /= cdf[-1]; cdf.searchsorted(u, "right").
+ * One thread per agent does exactly that in fp64 from the actor's float32 log-probabilities, with
+ * u = 53-bit uniform from Philox4x32-10 keyed by (seed; *counter, agent index) -- no RNG tensor, no
+ * softmax / cumsum round trips through HBM (24 B per agent in and out).
+ * logp: DEV float[n][n_a] (n_a <= 8); counter: DEV uint64 (read by the launch, then incremented by one
+ * on the stream, so hipGraph replays draw fresh numbers); actions: DEV int32[n].  Stateless.
+ */
+int32_t mm_sample_actions(const float *logp, int64_t n, int32_t n_a, uint64_t seed, uint64_t *counter,
+                          int32_t *actions, MMStream stream);
+
+/*
+ * The same with the actor network in front (marl/single_agent/Model_common.py:5-22: n_s -> hidden -> hidden
+ * -> n_a, ReLU, log-softmax; weights in torch nn.Linear layout [out][in], float32): one launch from the
+ * observation rows mm_step wrote to the next actions.  HIP build: f32-input MFMA, activations kept in
+ * registers (marl-mass_amd/csrc/mm_kernels.hip policy_kernel).  hidden must be 128 (the reference's only
+ * value), n_s <= 32, n_a <= 8.  obs: DEV float[n][n_s]; logp: optional DEV float[n][n_a] (the log-softmax
+ * the sample was drawn from); counter / actions as for mm_sample_actions.
+ */
+int32_t mm_policy_act(const float *obs, int64_t n, int32_t n_s, const float *W1, const float *b1, const float *W2,
+                      const float *b2, const float *W3, const float *b3, int32_t hidden, int32_t n_a, uint64_t seed,
+                      uint64_t *counter, int32_t *actions, float *logp, MMStream stream);
+
+/*
  * Diagnostics: evaluate one elementary function of include/mm_math.h element-wise
  * (fn: 0 sin, 1 cos, 2 tan, 3 atan, 4 asin, 5 exp, 6 log, 7 sqrt, 8 x/y with y = x2[i],
  * 9 x/y through the HIP path's constant-divisor form div_c (the oracle uses plain division)).

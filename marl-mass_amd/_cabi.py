@@ -132,7 +132,8 @@ class CLib(object):
 
     SYMBOLS = ["mm_abi_version", "mm_state_layout", "mm_create", "mm_destroy", "mm_set_config",
                "mm_reset", "mm_init_from_kinematics", "mm_observe", "mm_step", "mm_shield_qp",
-               "mm_set_metrics_buffer", "mm_last_error", "mm_math_eval", "mm_shield_actions"]
+               "mm_set_metrics_buffer", "mm_last_error", "mm_math_eval", "mm_shield_actions", "mm_sample_actions",
+               "mm_policy_act"]
 
     def __init__(self, path):
         if not os.path.exists(path):
@@ -155,6 +156,8 @@ class CLib(object):
         lib.mm_last_error.argtypes = [vp]
         lib.mm_math_eval.argtypes = [i32, i32, vp, vp, vp, vp]
         lib.mm_shield_actions.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.mm_sample_actions.argtypes = [vp, i64, i32, u64, vp, vp, vp]
+        lib.mm_policy_act.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, i32, i32, u64, vp, vp, vp, vp]
         lib.mm_last_error.restype = C.c_char_p
         for s in self.SYMBOLS:
             if s not in ("mm_abi_version", "mm_last_error"):

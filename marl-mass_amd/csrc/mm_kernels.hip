@@ -1892,6 +1892,206 @@ extern "C" int32_t mm_math_eval(int32_t fn, int32_t n, const double *x, const do
   return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_DEVICE;
 }
 
+// marl/mappo.py:220-236 exploration_action / action for a batch (include/mm_abi.h): softmax -> inverse-CDF
+// categorical sample, one thread per agent; HBM-bound by construction (4 n_a + 4 bytes per agent).
+__global__ __launch_bounds__(256) void sample_kernel(const float *__restrict__ logp, long long n, int n_a, uint64_t seed,
+                                                     const uint64_t *__restrict__ counter, int32_t *__restrict__ actions) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t ctr = *counter;
+  double cdf[8], acc = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (k < n_a) { acc = acc + mmm_exp((double)logp[i * n_a + k]); cdf[k] = acc; }
+  uint32_t o[4];
+  philox4x32((uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32) ^ 0x53414D50u,
+             (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  const double u = u53(o[0], o[1]);
+  int a = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (k < n_a) a += (cdf[k] / acc <= u) ? 1 : 0;  // searchsorted(cdf / cdf[-1], u, "right")
+  actions[i] = a < n_a - 1 ? a : n_a - 1;
+}
+__global__ void bump_kernel(uint64_t *counter) { *counter += 1; }
+extern "C" int32_t mm_sample_actions(const float *logp, int64_t n, int32_t n_a, uint64_t seed, uint64_t *counter,
+                                     int32_t *actions, MMStream stream) {
+  if (!logp || !actions || !counter || n < 0 || n_a < 1 || n_a > 8) return MM_ERR_INVALID_ARG;
+  if (n == 0) return MM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, logp, (long long)n, (int)n_a, seed, counter, actions);
+  hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, s, counter);
+  return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_DEVICE;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mm_policy_act: the actor forward of the rollout loop fused with the sampling above
+// (marl/single_agent/Model_common.py:5-22 ActorNetwork: n_s -> 128 -> 128 -> n_a, ReLU, log-softmax;
+// marl/mappo.py:220-236).  The one GEMM-shaped piece of the path, so it runs on the matrix cores:
+// f32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32 products and sums).
+//
+// Orientation: every layer is computed transposed, H_out^T [feature x agent] = W [out x in] . H_in^T, one
+// wave per 32 agents.  A 32x32 accumulator tile then has its agent on the lane and its features in the 16
+// registers, which is exactly the B-operand layout of the next layer's MFMAs (k = feature): activations
+// never leave the register file -- no LDS round trip, no transposes.  Lane (j = l & 31, h = l >> 5) holds
+// features row(r, h) = (r & 3) + 8 (r >> 2) + 4 h of a tile in register r, so k-step s of a 32-feature
+// chunk pairs feature row(s, 0) (lanes h = 0) with row(s, 1) (lanes h = 1); the weight fragments are
+// staged once per workgroup in LDS in that order (84 KB), read back as one conflict-free float4 per four
+// MFMAs.  Layer 3 (n_a <= 8 outputs) would waste 27/32 of a tile: done with 64 FMAs per output per lane
+// plus one cross-half add.  Then log-softmax (fp32) and the inverse-CDF sample (fp64), written by h = 0.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kPolHidden = 128;
+MM_DEV int frag_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+constexpr int kPolThreads = 512;  // 8 waves = 2 per SIMD: one wave's VALU tail (layer 3, sampling) overlaps the other's MFMAs
+__global__ __launch_bounds__(kPolThreads) void policy_kernel(const float *__restrict__ obs, long long n, int n_s,
+                                                        const float *__restrict__ W1, const float *__restrict__ b1,
+                                                        const float *__restrict__ W2, const float *__restrict__ b2,
+                                                        const float *__restrict__ W3, const float *__restrict__ b3, int n_a,
+                                                        uint64_t seed, const uint64_t *__restrict__ counter,
+                                                        int32_t *__restrict__ actions, float *__restrict__ logp_out) {
+  __shared__ float4 sW1[4][4][64];    // [out tile][k-step / 4][lane] : 16 KB
+  __shared__ float4 sW2[4][16][64];   // 64 KB
+  __shared__ float sW3[8][kPolHidden];
+  __shared__ float sB1[kPolHidden], sB2[kPolHidden], sB3[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  // ---- stage the weights in MFMA A-fragment order: A[i = l & 31][k = l >> 5] of step s is W[32 m + i][k(s, h)]
+  for (int t = tid; t < 4 * 4 * 64; t += kPolThreads) {
+    const int l = t & 63, q = (t >> 6) & 3, m = t >> 8;
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int k = frag_row(4 * q + u, l >> 5);
+      w[u] = k < n_s ? W1[(32 * m + (l & 31)) * n_s + k] : 0.0f;
+    }
+    sW1[m][q][l] = make_float4(w[0], w[1], w[2], w[3]);
+  }
+  for (int t = tid; t < 4 * 16 * 64; t += kPolThreads) {
+    const int l = t & 63, q = (t >> 6) & 15, m = t >> 10;
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int s = 4 * q + u;  // k-step 0..63: chunk s >> 4, step in chunk s & 15
+      w[u] = W2[(32 * m + (l & 31)) * kPolHidden + 32 * (s >> 4) + frag_row(s & 15, l >> 5)];
+    }
+    sW2[m][q][l] = make_float4(w[0], w[1], w[2], w[3]);
+  }
+  for (int t = tid; t < 8 * kPolHidden; t += kPolThreads) sW3[t / kPolHidden][t % kPolHidden] = (t / kPolHidden) < n_a ? W3[t] : 0.0f;
+  if (tid < kPolHidden) { sB1[tid] = b1[tid]; sB2[tid] = b2[tid]; }
+  if (tid < 8) sB3[tid] = tid < n_a ? b3[tid] : 0.0f;
+  __syncthreads();
+  const uint64_t ctr = *counter;
+  const long long ntiles = (n + 31) / 32;
+  constexpr int kWaves = kPolThreads / 64;
+  for (long long tile = (long long)blockIdx.x * kWaves + wave; tile < ntiles; tile += (long long)gridDim.x * kWaves) {
+    // the weight fragments are tile-invariant: without this the compiler hoists all 80 float4 LDS reads out of
+    // the persistent loop (320 registers) and spills the activations
+    asm volatile("" ::: "memory");
+    const long long ag = tile * 32 + j;
+    const bool live = ag < n;
+    float xk[16];  // B operand of layer 1: x[agent j][k(s, h)]
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+      const int k = frag_row(s, h);
+      xk[s] = (live && k < n_s) ? obs[ag * n_s + k] : 0.0f;
+    }
+    f32x16 h1[4], h2[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = sB1[32 * m + frag_row(r, h)];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float4 a = sW1[m][q][lane];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xk[4 * q + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xk[4 * q + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, xk[4 * q + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, xk[4 * q + 3], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) h1[m][r] = fmaxf(acc[r], 0.0f);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = sB2[32 * m + frag_row(r, h)];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float4 a = sW2[m][4 * c + q][lane];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, h1[c][4 * q + 0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, h1[c][4 * q + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, h1[c][4 * q + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, h1[c][4 * q + 3], acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) h2[m][r] = fmaxf(acc[r], 0.0f);
+    }
+    // ---- layer 3 + log-softmax + sample
+    float logit[8];
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+      float p = 0.0f;
+      if (o < n_a) {
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) p = fmaf(h2[m][r], sW3[o][32 * m + frag_row(r, h)], p);
+      }
+      p = p + __shfl_xor(p, 32, 64);
+      logit[o] = o < n_a ? p + sB3[o] : -INFINITY;
+    }
+    float mx = logit[0];
+#pragma unroll
+    for (int o = 1; o < 8; o++) mx = fmaxf(mx, logit[o]);
+    float se = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 8; o++) se += (o < n_a) ? expf(logit[o] - mx) : 0.0f;
+    const float lse = mx + logf(se);
+    if (live && h == 0) {
+      double cdf[8], acc = 0;
+#pragma unroll
+      for (int o = 0; o < 8; o++) {
+        const float lp = logit[o] - lse;
+        if (o < n_a) {
+          if (logp_out) logp_out[ag * n_a + o] = lp;
+          acc = acc + mmm_exp((double)lp);
+          cdf[o] = acc;
+        }
+      }
+      uint32_t w4[4];
+      philox4x32((uint32_t)ag, (uint32_t)((uint64_t)ag >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32) ^ 0x53414D50u,
+                 (uint32_t)seed, (uint32_t)(seed >> 32), w4);
+      const double u = u53(w4[0], w4[1]);
+      int a = 0;
+#pragma unroll
+      for (int o = 0; o < 8; o++)
+        if (o < n_a) a += (cdf[o] / acc <= u) ? 1 : 0;
+      actions[ag] = a < n_a - 1 ? a : n_a - 1;
+    }
+  }
+}
+extern "C" int32_t mm_policy_act(const float *obs, int64_t n, int32_t n_s, const float *W1, const float *b1, const float *W2,
+                                 const float *b2, const float *W3, const float *b3, int32_t hidden, int32_t n_a, uint64_t seed,
+                                 uint64_t *counter, int32_t *actions, float *logp, MMStream stream) {
+  if (!obs || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !counter || !actions) return MM_ERR_INVALID_ARG;
+  if (n < 0 || n_s < 1 || n_s > 32 || hidden != kPolHidden || n_a < 1 || n_a > 8) return MM_ERR_INVALID_ARG;
+  if (n == 0) return MM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const long long ntiles = (n + 31) / 32;
+  constexpr int kW = kPolThreads / 64;
+  const unsigned grid = (unsigned)(ntiles < kW * 256 ? (ntiles + kW - 1) / kW : 256);  // one persistent workgroup per CU
+  hipLaunchKernelGGL(policy_kernel, dim3(grid), dim3(kPolThreads), 0, s, obs, (long long)n, (int)n_s, W1, b1, W2, b2, W3, b3, (int)n_a,
+                     seed, counter, actions, logp);
+  hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, s, counter);
+  return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_DEVICE;
+}
+
 #ifdef MM_STAMPS
 extern "C" int32_t mm_debug_read_stamps(unsigned long long *out16, int32_t reset) {
   hipError_t rc = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);

@@ -75,14 +75,20 @@ class DeviceRollout(object):
     """MAPPO.interact for a whole env batch; see the module docstring."""
 
     def __init__(self, env, actor, critic=None, roll_out_n_steps=100, reward_gamma=0.99, reward_scale=20.0,
-                 reward_type="regionalR", generator=None, use_graph=False):
+                 reward_type="regionalR", generator=None, use_graph=False, sample_seed=0, fused_policy=True):
         assert reward_type in ("regionalR", "global_R")  # marl/mappo.py:39
         self.env, self.actor, self.critic = env, actor, critic
         self.T, self.gamma, self.reward_scale, self.reward_type = roll_out_n_steps, reward_gamma, reward_scale, reward_type
         self.generator = generator
         self.n_a = env.n_a
+        self.sample_seed = int(sample_seed) & 0xFFFFFFFFFFFFFFFF
+        # fused actor + sampling launch for the reference's ActorNetwork (hidden 128); anything else goes
+        # through the module's own forward
+        self.fused_policy = bool(fused_policy) and type(actor) is ActorNetwork and actor.fc2.weight.shape[0] == 128 \
+            and next(actor.parameters()).dtype == torch.float32
         self.obs, _ = env.reset()
         self.obs = self.obs.clone()
+        self._sample_counter = torch.zeros(1, dtype=torch.int64, device=self.obs.device)  # advanced by mm_sample_actions
         self.use_graph = bool(use_graph)
         if self.use_graph:
             if self.obs.device.type != "cuda":
@@ -95,10 +101,29 @@ class DeviceRollout(object):
     def act(self, obs):
         """exploration_action / action (marl/mappo.py:220-236): sample from softmax(actor(obs))."""
         E, N, S = obs.shape
+        if self.generator is None and self.fused_policy and type(self.actor) is ActorNetwork and obs.dtype == torch.float32:
+            # actor forward + sampling in ONE launch (mm_policy_act: f32 MFMA, activations in registers)
+            a, clib = self.actor, self.env.clib
+            actions = torch.empty(E * N, dtype=torch.int32, device=obs.device)
+            ptr = lambda t: t.detach().contiguous().data_ptr()  # noqa: E731  (nn.Linear parameters are contiguous)
+            clib.check(clib.lib.mm_policy_act(obs.contiguous().data_ptr(), E * N, S, ptr(a.fc1.weight), ptr(a.fc1.bias),
+                                              ptr(a.fc2.weight), ptr(a.fc2.bias), ptr(a.fc3.weight), ptr(a.fc3.bias),
+                                              a.fc2.weight.shape[0], self.n_a, self.sample_seed,
+                                              self._sample_counter.data_ptr(), actions.data_ptr(), None, self.env._stream()))
+            return actions.view(E, N)
         logp = self.actor(obs.reshape(E * N, S).float())
         # np.random.choice(n_a, p=softmax) (marl/mappo.py:229) is inverse-CDF sampling: cdf.searchsorted(u, "right").
-        # Same here, with a device uniform (also keeps the op list free of torch.multinomial's device-side
-        # asserts, which do not survive hipGraph replay).
+        if self.generator is None:
+            # fused in the library (mm_sample_actions): softmax -> cdf -> search, Philox uniform per agent, one
+            # pass over 24 B/agent instead of five elementwise / scan kernels over fp64 temporaries
+            logp = logp.contiguous()
+            actions = torch.empty(E * N, dtype=torch.int32, device=obs.device)
+            clib = self.env.clib
+            stream = self.env._stream()
+            clib.check(clib.lib.mm_sample_actions(logp.data_ptr(), E * N, self.n_a, self.sample_seed,
+                                                  self._sample_counter.data_ptr(), actions.data_ptr(), stream))
+            return actions.view(E, N)
+        # caller-supplied torch generator: same arithmetic with torch ops
         cdf = logp.exp().double().cumsum(-1)
         cdf = cdf / cdf[:, -1:]
         u = torch.rand(E * N, 1, dtype=torch.float64, device=obs.device, generator=self.generator)

@@ -1499,3 +1499,66 @@ int32_t orc_set_threads(int32_t n) { if (n > 0) omp_set_num_threads(n); return o
 #else
 int32_t orc_set_threads(int32_t n) { (void)n; return 1; }
 #endif
+
+/* marl/mappo.py:220-236 exploration_action / action for a batch (see include/mm_abi.h).  Always uses the
+ * bit-reproducible exp of mm_math.h so that the HIP library draws the same actions from the same key. */
+int32_t mm_sample_actions(const float *logp, int64_t n, int32_t n_a, uint64_t seed, uint64_t *counter,
+                          int32_t *actions, MMStream stream) {
+  (void)stream;
+  if (!logp || !actions || !counter || n < 0 || n_a < 1 || n_a > 8) return MM_ERR_INVALID_ARG;
+  const uint64_t ctr = *counter;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    double cdf[8], acc = 0;
+    for (int k = 0; k < n_a; k++) { acc = acc + mmm_exp((double)logp[i * n_a + k]); cdf[k] = acc; }
+    uint32_t o[4];
+    philox4x32((uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)ctr, (uint32_t)(ctr >> 32) ^ 0x53414D50u,
+               (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    const double u = ((o[0] >> 5) * 67108864.0 + (o[1] >> 6)) / 9007199254740992.0;
+    int a = 0;
+    for (int k = 0; k < n_a; k++) a += (cdf[k] / cdf[n_a - 1] <= u) ? 1 : 0; /* searchsorted(cdf / cdf[-1], u, "right") */
+    actions[i] = a < n_a - 1 ? a : n_a - 1;
+  }
+  *counter = ctr + 1;
+  return MM_OK;
+}
+
+/* Actor forward (Model_common.py:5-22) + the sampling above; plain fp32 loops in natural order.  The HIP
+ * build sums the same fp32 products in MFMA order, so log-probabilities agree to rounding (tests: 1e-4),
+ * and given equal log-probabilities the drawn actions are identical. */
+int32_t mm_policy_act(const float *obs, int64_t n, int32_t n_s, const float *W1, const float *b1, const float *W2,
+                      const float *b2, const float *W3, const float *b3, int32_t hidden, int32_t n_a, uint64_t seed,
+                      uint64_t *counter, int32_t *actions, float *logp, MMStream stream) {
+  if (!obs || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !counter || !actions) return MM_ERR_INVALID_ARG;
+  if (n < 0 || n_s < 1 || n_s > 32 || hidden != 128 || n_a < 1 || n_a > 8) return MM_ERR_INVALID_ARG;
+  float *lp_all = logp ? logp : (float *)malloc((size_t)(n > 0 ? n : 1) * n_a * sizeof(float));
+  if (!lp_all) return MM_ERR_INVALID_ARG;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n; i++) {
+    float h1[128], h2[128], lg[8];
+    for (int o = 0; o < 128; o++) {
+      float acc = b1[o];
+      for (int k = 0; k < n_s; k++) acc = fmaf(W1[o * n_s + k], obs[i * n_s + k], acc);
+      h1[o] = acc > 0 ? acc : 0;
+    }
+    for (int o = 0; o < 128; o++) {
+      float acc = b2[o];
+      for (int k = 0; k < 128; k++) acc = fmaf(W2[o * 128 + k], h1[k], acc);
+      h2[o] = acc > 0 ? acc : 0;
+    }
+    float mx = -INFINITY;
+    for (int o = 0; o < n_a; o++) {
+      float acc = 0;
+      for (int k = 0; k < 128; k++) acc = fmaf(h2[k], W3[o * 128 + k], acc);
+      lg[o] = acc + b3[o];
+      mx = lg[o] > mx ? lg[o] : mx;
+    }
+    float se = 0;
+    for (int o = 0; o < n_a; o++) se += expf(lg[o] - mx);
+    const float lse = mx + logf(se);
+    for (int o = 0; o < n_a; o++) lp_all[i * n_a + o] = lg[o] - lse;
+  }
+  int32_t rc = mm_sample_actions(lp_all, n, n_a, seed, counter, actions, stream);
+  if (!logp) free(lp_all);
+  return rc;
+}

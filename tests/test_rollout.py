@@ -138,3 +138,100 @@ def test_evaluate_matches_per_episode_loop():
         assert bool(ext["crash_count"][e]) == bool(info["crashed"][0].any())
         assert abs(float(ext["merge_percents"][e]) - float(info["merge_percent"][0])) <= 1e-12
         assert ext["min_headway"] <= mh + 1e-15
+
+
+def _sample(clib, logp, seed, counter):
+    out = torch.empty(logp.shape[0], dtype=torch.int32, device=logp.device)
+    stream = None
+    if logp.is_cuda:
+        import ctypes
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    clib.check(clib.lib.mm_sample_actions(logp.data_ptr(), logp.shape[0], logp.shape[1], seed, counter.data_ptr(),
+                                          out.data_ptr(), stream))
+    return out
+
+
+def test_sample_actions_distribution_and_counter():
+    """mm_sample_actions (oracle build): inverse-CDF sampling of softmax probabilities, fresh numbers per call."""
+    clib = oracle_env.library()
+    torch.manual_seed(1)
+    n = 200000
+    logp = torch.log_softmax(torch.tensor([[0.3, 1.2, -0.5, 0.0, 2.0]]), -1).repeat(n, 1).contiguous()
+    ctr = torch.zeros(1, dtype=torch.int64)
+    a0 = _sample(clib, logp, 5, ctr)
+    a1 = _sample(clib, logp, 5, ctr)
+    assert int(ctr) == 2 and not torch.equal(a0, a1)
+    freq = torch.bincount(a0.long(), minlength=5).double() / n
+    assert torch.allclose(freq, logp[0].exp().double(), atol=5e-3)
+    ctr.zero_()
+    assert torch.equal(_sample(clib, logp, 5, ctr), a0)          # same key -> same draw
+    one_hot = torch.full((7, 5), -float("inf")); one_hot[torch.arange(7), torch.arange(7) % 5] = 0.0
+    assert _sample(clib, one_hot.contiguous(), 9, ctr).tolist() == [0, 1, 2, 3, 4, 0, 1]
+    with pytest.raises(ValueError):
+        _sample(clib, torch.zeros(4, 9), 0, ctr)
+
+
+@pytest.mark.gpu
+def test_sample_actions_hip_equals_oracle():
+    from marl_mass_amd import hip_library
+    torch.manual_seed(2)
+    n = 1 << 18
+    logp = torch.log_softmax(torch.randn(n, 5) * 2, -1).contiguous()
+    c_cpu, c_gpu = torch.tensor([41], dtype=torch.int64), torch.tensor([41], dtype=torch.int64, device="cuda")
+    for _ in range(2):
+        a_cpu = _sample(oracle_env.library(), logp, 1234567, c_cpu)
+        a_gpu = _sample(hip_library(), logp.cuda(), 1234567, c_gpu)
+        assert torch.equal(a_gpu.cpu(), a_cpu)
+    assert int(c_gpu) == int(c_cpu) == 43
+
+
+def _policy_act(clib, obs, actor, seed, counter, want_logp=True):
+    import ctypes
+    n, S = obs.shape
+    acts = torch.empty(n, dtype=torch.int32, device=obs.device)
+    logp = torch.empty(n, 5, dtype=torch.float32, device=obs.device) if want_logp else None
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream) if obs.is_cuda else None
+    p = lambda t: t.detach().contiguous().data_ptr()  # noqa: E731
+    clib.check(clib.lib.mm_policy_act(obs.data_ptr(), n, S, p(actor.fc1.weight), p(actor.fc1.bias), p(actor.fc2.weight),
+                                      p(actor.fc2.bias), p(actor.fc3.weight), p(actor.fc3.bias), 128, 5, seed, counter.data_ptr(),
+                                      acts.data_ptr(), logp.data_ptr() if want_logp else None, stream))
+    return acts, logp
+
+
+@pytest.mark.parametrize("n_s,n", [(30, 1000), (25, 77)])
+def test_policy_act_oracle_matches_torch(n_s, n):
+    """mm_policy_act (oracle build) == ActorNetwork forward (Model_common.py:5-22) + mm_sample_actions."""
+    torch.manual_seed(4)
+    actor = ActorNetwork(n_s, 128, 5)
+    obs = torch.randn(n, n_s)
+    ctr = torch.tensor([3], dtype=torch.int64)
+    acts, logp = _policy_act(oracle_env.library(), obs, actor, 11, ctr)
+    with torch.no_grad():
+        ref = actor(obs)
+    assert torch.allclose(logp, ref, atol=2e-5, rtol=0) and int(ctr) == 4
+    ctr2 = torch.tensor([3], dtype=torch.int64)
+    assert torch.equal(acts, _sample(oracle_env.library(), logp.contiguous(), 11, ctr2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_s,n", [(30, 65536 * 8 + 13), (25, 1000), (30, 31)])
+def test_policy_act_hip_mfma(n_s, n):
+    """The fused f32-MFMA actor + sampling launch vs torch fp32 (log-probabilities to rounding) and vs the
+    oracle's sampler on the kernel's own log-probabilities (actions exact); ragged n, both obs widths."""
+    from marl_mass_amd import hip_library
+    torch.manual_seed(5)
+    actor = ActorNetwork(n_s, 128, 5).cuda()
+    with torch.no_grad():  # asymmetric, non-trivial scales in every layer
+        actor.fc1.bias.uniform_(-0.5, 0.5); actor.fc2.bias.uniform_(-0.5, 0.5); actor.fc3.bias.uniform_(-1, 1)
+        actor.fc3.weight.mul_(3.0)
+    obs = (torch.randn(n, n_s, device="cuda") * 1.5).contiguous()
+    ctr = torch.tensor([8], dtype=torch.int64, device="cuda")
+    acts, logp = _policy_act(hip_library(), obs, actor, 99, ctr)
+    with torch.no_grad():
+        ref = actor(obs)
+    assert float((logp - ref).abs().max()) <= 2e-4
+    assert int(ctr) == 9
+    c2 = torch.tensor([8], dtype=torch.int64)
+    assert torch.equal(acts.cpu(), _sample(oracle_env.library(), logp.cpu().contiguous(), 99, c2))
+    acts2, _ = _policy_act(hip_library(), obs, actor, 99, ctr, want_logp=False)  # counter advanced: new draw
+    assert not torch.equal(acts, acts2) or n < 64
