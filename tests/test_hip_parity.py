@@ -256,6 +256,35 @@ def test_full_size_bit_exact_vs_oracle():
     assert int(gpu.env_i32[abi.EP["EPISODE"]].max()) >= 2, "some envs must have auto-reset"
 
 
+@pytest.mark.parametrize("name,env_id,safety,E,N,eta,tau", [
+    ("c2", "merge-multi-agent-v0", "none", 4096, 4, 0.0, 1.2),
+    ("c3", "merge-multi-agent-v1", "cbf-avs_cint", 4096, 4, 0.03125, 0.5),
+    ("c4", "merge-multi-agent-v1", "cbf-cav", 16384, 8, 0.03125, 0.5),
+    ("c5-per-gpu", "merge-multi-agent-v1", "cbf-cav", 8192, 8, 0.03125, 0.5)])
+def test_baseline_configs_bit_exact(name, env_id, safety, E, N, eta, tau):
+    """BASELINE.json configs c2..c5 at their own sizes: 30 steps with the bench's action
+    distribution, every output of every step equal to the oracle's."""
+    kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau}, cbf_eta=eta, cbf_tau=tau,
+              seed=1000, auto_reset=True)
+    oracle_env.library().lib.orc_set_threads(16)
+    gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
+    gpu.reset()
+    cpu.reset()
+    ph = (torch.arange(E, dtype=torch.int32) * 13) % 95  # every phase of an episode is present
+    gpu.env_i32[abi.EP["STEPS"]] = ph.cuda()
+    cpu.env_i32[abi.EP["STEPS"]] = ph
+    g = torch.Generator().manual_seed(17)
+    p = torch.tensor([0.1, 0.6, 0.1, 0.1, 0.1])
+    for t in range(30):
+        a = torch.multinomial(p, E * N, True, generator=g).view(E, N).int()
+        og, rg, dg, ig = gpu.step(a.cuda())
+        oc, rc, dc, ic = cpu.step(a)
+        assert torch.equal(og.cpu(), oc) and torch.equal(rg.cpu(), rc) and torch.equal(dg.cpu(), dc), (name, t)
+        for k in ("agents_rewards", "regional_rewards", "agents_dones", "average_speed", "traffic_speed", "min_headway", "crashed", "action_mask"):
+            assert torch.equal(ig[k].cpu(), ic[k]), (name, t, k)
+    assert torch.equal(gpu.u8.cpu(), cpu.u8) and torch.equal(gpu.f64.cpu().nan_to_num(), cpu.f64.nan_to_num())
+
+
 @pytest.mark.parametrize("safety,n_hdv,lateral,N", [("cbf-cav", 0, "steer", 8), ("cbf-avs_cint", 0, "steer", 8), ("cbf-cav", 3, "steer", 8),
                                                       ("cbf-cav", 0, "steer_vel", 8), ("cbf-cav", 0, "steer", 4), ("cbf-cav", 0, "steer", 12),
                                                       ("cbf-avs_cint", 0, "steer", 2), ("cbf-cav", 5, "steer", 11), ("none", 2, "steer", 4)])
