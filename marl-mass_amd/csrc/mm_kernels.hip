@@ -931,7 +931,10 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
     int new_flags = v.flags;
 
     if (SHIELDED && __any(shield_on)) {
-      bool serial = (c.debug_flags & 1) != 0;
+      // The general kernels (HDVs / steer_vel) run the literal sweep only: with HDVs on the ramp the
+      // digital-twin case sends most sub-steps to the fallback anyway, and without the parallel form the
+      // kernel is half the code and half the spills (measured 2.30 -> 1.04 ms at 65536 x (4 + 4) MASS).
+      bool serial = MIXED || (c.debug_flags & 1) != 0;
       ShieldOut so;
       memset(&so, 0, sizeof so);
       if (!serial) {
