@@ -2,20 +2,22 @@
 //
 // Mapping (CDNA4, wave64): one LANE per vehicle, the G = pow2 >= N lanes of an env are contiguous
 // in a wave ("env group"), 64/G envs per wave, 256-thread blocks.  All cross-vehicle reads of an
-// env (neighbour search, collision, observation, rewards, shield) are wave shuffles inside the
-// group: no LDS tiles, no __syncthreads, no inter-workgroup traffic.  One launch = one env.step
-// for every env: 3 simulation sub-steps + rewards/info + optional re-spawn + observation.
+// env (neighbour search, collision, observation, rewards, shield) are DPP / bpermute exchanges
+// inside the group: no inter-workgroup traffic.  LDS holds per-thread "cold slots" (register
+// relief, no sharing) and, after one barrier, the transposed observation rows.  One launch = one
+// env.step for every env: 3 simulation sub-steps + rewards/info + optional re-spawn + observation.
 //
 // Sub-step structure (reference: abstract.py:512-532, road.py:269-292):
-//   act      per-lane  ControlledVehicle.act: follow_road, steering/speed control
+//   act      per-lane  ControlledVehicle.act (follow_road, steering/speed control); IDM/MOBIL for HDVs
 //   predict  per-lane  bicycle integration + lane argmin + corner tests for the nominal steering
-//                      (and for the LC-veto steering when it can differ) -- ALL transcendentals
-//                      live here, at full lane utilisation
-//   sweep    serial    front-to-back Gauss-Seidel over the env's vehicles (road.py:286): the CBF
-//                      state assembly + closed-form QP + LC veto of one vehicle per stage; only
-//                      selects between the predicted post-states, so a stage is ~40 shuffles and
-//                      ~150 fp64 ops.  Followers see leaders' committed post-step state.
-//   collide  per-lane  pair tests by xor-shuffle; the rare order-dependent speed fix-up is serial
+//                      (lazily also for the LC-veto steering) -- ALL transcendentals live here
+//   sweep              the reference's front-to-back Gauss-Seidel over the env's vehicles (road.py:286)
+//                      as a parallel fixed point (classification pass, MASS acceleration rounds, veto
+//                      passes) with the literal serial sweep as fallback / validation form; the general
+//                      kernels (MIXED) run the serial form only.  See DESIGN.md section 2.
+//   collide  per-lane  pair tests by DPP exchange; the rare order-dependent speed fix-up is serial
+// Also here: reset / observe / stand-alone shield / QP kernels, the categorical sampler and the f32-MFMA
+// policy kernel of the rollout counterpart.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
