@@ -716,18 +716,24 @@ MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
 #ifndef MM_MIN_WAVES
 #define MM_MIN_WAVES 2  // 2 waves/SIMD: measured 0.62 ms vs 0.98 (1) / 0.92 (3, spills) at 65536x8 MASS
 #endif
-// The shielded 16-lane groups carry twice the partner state: at 2 waves/SIMD they spill ~1 KB/lane
-// to scratch; with the whole 512-register file (1 wave/SIMD) they run 1.6x faster (1.22 vs 1.93 ms
-// at 32768 x 12 MASS) -- and it is the configuration the toolchain compiles correctly (DESIGN.md
-// "toolchain note").
-template <int G, int SHIELD>
-constexpr int step_min_waves() { return (G == 16 && SHIELD != MM_SHIELD_NONE) ? 1 : MM_MIN_WAVES; }
+// The 16-lane groups of the parallel-form kernel (HSS, CAV-only) carry twice the partner state: at
+// 2 waves/SIMD they spill ~1 KB/lane to scratch; with the whole 512-register file (1 wave/SIMD) they run
+// 1.6x faster.  The serial-only kernels (MASS, general) need no spills at 2 waves/SIMD at any G.
+template <int G, int SHIELD, bool MIXED>
+constexpr int step_min_waves() { return (G == 16 && SHIELD == MM_SHIELD_HSS && !MIXED) ? 1 : MM_MIN_WAVES; }
 template <int G, int KIND, int SHIELD, bool MIXED>
-__global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
+__global__ __launch_bounds__(256, (step_min_waves<G, SHIELD, MIXED>())) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
                                                    MMStepOut out, double *metrics) {
   constexpr bool LC = (KIND == MM_ENV_V1);
   constexpr bool SHIELDED = LC && (SHIELD != MM_SHIELD_NONE);
   constexpr bool MASS = (SHIELD == MM_SHIELD_MASS);
+  // Form of the shield sweep.  MASS and the general kernels (HDVs / steer_vel) run the literal front-to-back
+  // sweep ONLY: compiled on its own it needs no VGPR spills (scratch 16 B/lane vs 248 B with both forms) and
+  // at 65536 x 8 MASS it ties the parallel fixed-point form (0.46 vs 0.45 ms) -- the coupling through the
+  // leaders' decided accelerations costs the parallel form its rounds -- while with HDVs the digital-twin case
+  // sent most sub-steps to the fallback anyway (2.30 -> 1.04 ms).  HSS has no such coupling: its parallel
+  // form is 14 % faster (0.38 vs 0.44 ms) and is what runs, with the literal sweep as fallback.
+  constexpr bool kSerialOnly = MIXED || MASS;
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long e = gtid / G;
   const int a = (int)(gtid % G);
@@ -771,7 +777,7 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
   // 100 B/lane of scratch costs ~8 % of the kernel): the LC-veto candidate B, the history records,
   // the previous safe action, the target speed, and the 7..15 sort keys of the classification pass.
   enum { C_B = 0, C_H1X = 7, C_H1VX, C_H2X, C_H2VX, C_SSTEER, C_SACC, C_TSPEED, C_A = 14, kColdB = 21 };
-  constexpr int kColdN = kColdB + (G - 1);
+  constexpr int kColdN = kColdB + (kSerialOnly ? 0 : G - 1);  // the sort keys are a parallel-form temporary
   static_assert(kColdN * 2048 >= 4 * 64 * 30 * 4, "the obs staging must fit in the cold slots");
   __shared__ double s_cold[kColdN][256];
   const int tid = threadIdx.x;
@@ -933,10 +939,9 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD>())) void step_kerne
     int new_flags = v.flags;
 
     if (SHIELDED && __any(shield_on)) {
-      // The general kernels (HDVs / steer_vel) run the literal sweep only: with HDVs on the ramp the
-      // digital-twin case sends most sub-steps to the fallback anyway, and without the parallel form the
-      // kernel is half the code and half the spills (measured 2.30 -> 1.04 ms at 65536 x (4 + 4) MASS).
-      bool serial = MIXED || (c.debug_flags & 1) != 0;
+      // Which form runs is a compile-time property of the instantiation (kSerialOnly, above); debug_flags
+      // bit0 forces the literal sweep in the kernels that carry both.
+      bool serial = kSerialOnly || (c.debug_flags & 1) != 0;
       ShieldOut so;
       memset(&so, 0, sizeof so);
       if (!serial) {
