@@ -536,6 +536,9 @@ struct Neigh {  // the three slots of multi_agent_state (:85-257) after the obst
   double ol_x, ol_vx, ol_acc, ol_g;  // leader: state_hist[-2].x / .vx, its action and g.vx (MASS)
   double oa_x, oa_vx, oa_acc, oa_g;  // front adjacent
   double oar_x, oar_vx;              // rear adjacent: current to_dict()
+  // literal sweep: the products g2*u2 / g4*u4 of the CBF rows as the PUBLISHING lane computed them from its
+  // own record (same operands, same order as below), so a stage fetches 2 values per slot instead of 4
+  double ol_gu, oa_gu;
 };
 struct ShieldOut {
   double acc, us0;  // derived acceleration, u_safe[0]
@@ -547,16 +550,17 @@ struct ShieldOut {
 };
 template <bool MASS>
 MM_DEV unsigned obstacle_override(Neigh &nb, double x, double y) {  // decentral_layer.py:213-246
+  // (a replaced slot has u = max(0, 0 + acc dt) = 0 for acc in {0, -12.5}, so its g*u product is +0)
   unsigned replaced = 0;  // bit0: leader slot, bit1: adjacent slot now hold the obstacle at (420, 4)
   if (!(x > kObstX)) {
     const double ady = fabs(kObstY - y);
     if ((!nb.has_ol || kObstX <= nb.ol_x) && ady <= 2) {
-      nb.has_ol = true; nb.ol_x = kObstX; nb.ol_vx = 0.0;
+      nb.has_ol = true; nb.ol_x = kObstX; nb.ol_vx = 0.0; nb.ol_gu = 0.0;
       if (MASS) { nb.ol_acc = 0; nb.ol_g = 0; }
       replaced |= 1u;
     }
     if ((!nb.has_oa || kObstX <= nb.oa_x) && (2 < ady && ady <= 4)) {
-      nb.has_oa = true; nb.oa_x = kObstX; nb.oa_vx = 0.0;
+      nb.has_oa = true; nb.oa_x = kObstX; nb.oa_vx = 0.0; nb.oa_gu = 0.0;
       if (MASS) { nb.oa_acc = 0; nb.oa_g = 0; nb.constrain_adj = false; }
       replaced |= 2u;
     }
@@ -613,18 +617,34 @@ MM_DEV ShieldStatic shield_static(const DevCfg &c, const Veh &v, double cpsi, bo
   s.can_abort_lc = !offL && !offR;  // :728-736 on the pre-step pose
   return s;
 }
+// The neighbours' predicted speed u = max(0, vx + acc dt) and its CBF-row product (g dt) u, from one record.
 template <bool MASS>
+MM_DEV double slot_gu(double vx, double acc, double g, double dt) {
+  double u = vx + acc * dt;
+  u = u > 0 ? u : 0;
+  return (MASS ? g * dt : 1 * dt) * u;
+}
+// PRE: nb.ol_gu / nb.oa_gu already hold those products (computed by the lanes that own the records)
+template <bool MASS, bool PRE = false>
 MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s, const Neigh &nb) {
   const double dt = c.dt, eta = c.eta;
   ShieldOut o;
-  double u2 = 0, u4 = 0;
-  if (nb.has_ol) { u2 = nb.ol_vx + nb.ol_acc * dt; u2 = u2 > 0 ? u2 : 0; }
-  if (nb.has_oa) { u4 = nb.oa_vx + nb.oa_acc * dt; u4 = u4 > 0 ? u4 : 0; }
+  double g2u2, g4u4;
+  if (PRE) {
+    g2u2 = nb.has_ol ? nb.ol_gu : 0.0;
+    g4u4 = nb.has_oa ? nb.oa_gu : 0.0;
+  } else {
+    double u2 = 0, u4 = 0;
+    if (nb.has_ol) { u2 = nb.ol_vx + nb.ol_acc * dt; u2 = u2 > 0 ? u2 : 0; }
+    if (nb.has_oa) { u4 = nb.oa_vx + nb.oa_acc * dt; u4 = u4 > 0 ? u4 : 0; }
+    g2u2 = s.g2 * u2;
+    g4u4 = s.g4 * u4;
+  }
   const double g0u0 = s.g0 * s.u0;
-  const double h0 = s.base0 + (-g0u0 + s.g2 * u2);
+  const double h0 = s.base0 + (-g0u0 + g2u2);
   double h3 = __builtin_nan(""), hc = h0;
   if (s.cadj) {
-    h3 = s.base3 + (-g0u0 + s.g4 * u4);
+    h3 = s.base3 + (-g0u0 + g4u4);
     hc = h3 < h0 ? h3 : h0;
   }
   // exact KKT point of min 1/2(d^2 + e^2 + 1e18 s^2) s.t. a d - s <= hc, lo <= d <= hi
@@ -636,13 +656,13 @@ MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s
   double us0 = s.u0 + d;
   {  // update_status (cbf.py:341-351) on u_status = [u_safe (QP), u_ll[2:]]
     const double hls_lon = s.px_lon + s.q_lon;
-    const double hlds_lon = s.px_lon + ((-s.g0) * us0 + s.g2 * u2) + s.q_lon;
+    const double hlds_lon = s.px_lon + ((-s.g0) * us0 + g2u2) + s.q_lon;
     o.lon_safe = hls_lon >= -1e-6;
     o.lon_invariant = (hlds_lon + (eta - 1) * hls_lon) >= -1e-6;
     o.headway = (s.px_lon - kVehLength) / s.evx;
   }
   // is_lc_allowed (cbf.py:324-339)
-  const double hlds_lona = s.px_lona + ((-s.g0) * us0 + s.g4 * u4) + s.q_lona;
+  const double hlds_lona = s.px_lona + ((-s.g0) * us0 + g4u4) + s.q_lona;
   const double hlds_lonr = s.px_lonr + (s.g0 * us0 + (-s.g6) * s.u6) + s.q_lonr;
   const double inv_lona = hlds_lona + (eta - 1) * s.hls_lona, inv_lonr = hlds_lonr + (eta - 1) * s.hls_lonr;
   const bool lc_allowed = ((s.hls_lona >= 0) && inv_lona >= 0) && ((s.hls_lonr >= 0) && inv_lonr >= 0);
@@ -664,10 +684,10 @@ MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s
   o.qt.margin = fmin(fmin(s.hls_lona, inv_lona), fmin(s.hls_lonr, inv_lonr));
   return o;
 }
-template <bool MASS>
+template <bool MASS, bool PRE = false>
 MM_DEV ShieldOut shield_eval(const DevCfg &c, const Veh &v, double cpsi, bool offL, bool offR, const Neigh &nb) {
   const ShieldStatic s = shield_static<MASS>(c, v, cpsi, offL, offR, nb);
-  return shield_dyn<MASS>(c, v, s, nb);
+  return shield_dyn<MASS, PRE>(c, v, s, nb);
 }
 
 // Relation of vehicle `o` (as the ego currently sees it) to the ego: the branch conditions of the
@@ -1079,6 +1099,8 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD, MIXED>())) void ste
           // HDVs take no part in the shield: publish their stepped view when the sweep passes them
           // (done below by rank), here only note that their record [-2] after stepping is the old [-1]
         }
+        // the g*u product an ego's CBF rows take from my record (slot_gu), recomputed whenever the record changes
+        double wgu = slot_gu<MASS>(whvx, MASS ? wacc : kCbfAccLo, wg, dt);
         bool w_stepped = false;  // my published view is already the post-step one
         double twin_shift = 0;   // in-place edits egos made to my history record this sub-step
         for (int r = 0; r < st.N; r++) {
@@ -1088,6 +1110,7 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD, MIXED>())) void ste
             const Cand ca = chosen(false);
             wx = ca.x; wy = ca.y; wh = ca.h; wlane = ca.lane; wnl = ca.nl; woffL = ca.offL; woffR = ca.offR;
             whx = s_cold[C_H1X][tid]; whvx = s_cold[C_H1VX][tid]; w_stepped = true; twin_shift = 0;
+            wgu = slot_gu<MASS>(whvx, MASS ? wacc : kCbfAccLo, wg, dt);
           }
           const unsigned sel = group_ballot<G>(shield_on && rank == r, gb);
           const bool has = sel != 0;
@@ -1114,14 +1137,20 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD, MIXED>())) void ste
           if (is_twin) { whx = whx + 0.5 * e_vx; twin_shift = 1; }
           unsigned f_tw = is_twin ? ((unsigned)(15 - pos) << 5 | (unsigned)a << 1) : none;
           unsigned w = f_ol | f_oa << 10 | f_oar << 20;
-#pragma unroll
-          for (int m = 1; m < G; m <<= 1) {
-            unsigned o = (unsigned)__shfl_xor((int)w, m, 64);
-            unsigned m0 = min(w & 0x3FFu, o & 0x3FFu), m1 = min((w >> 10) & 0x3FFu, (o >> 10) & 0x3FFu),
-                     m2 = min((w >> 20) & 0x3FFu, (o >> 20) & 0x3FFu);
+          // butterfly min over the group by DPP (one VALU-rate op per exchange; after xor 1, 2 a quad is
+          // uniform, so row_half_mirror serves as xor 4, then row_ror:8 as xor 8)
+          auto red = [&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            const unsigned o = (unsigned)dppx_i<m>((int)w);
+            const unsigned m0 = min(w & 0x3FFu, o & 0x3FFu), m1 = min((w >> 10) & 0x3FFu, (o >> 10) & 0x3FFu),
+                           m2 = min((w >> 20) & 0x3FFu, (o >> 20) & 0x3FFu);
             w = m0 | m1 << 10 | m2 << 20;
-            if (MIXED) f_tw = min(f_tw, (unsigned)__shfl_xor((int)f_tw, m, 64));
-          }
+            if (MIXED) f_tw = min(f_tw, (unsigned)dppx_i<m>((int)f_tw));
+          };
+          if constexpr (G >= 2) red(std::integral_constant<int, 1>{});
+          if constexpr (G >= 4) red(std::integral_constant<int, 2>{});
+          if constexpr (G >= 8) red(std::integral_constant<int, 7>{});
+          if constexpr (G >= 16) red(std::integral_constant<int, 8>{});
           f_ol = w & 0x3FFu; f_oa = (w >> 10) & 0x3FFu; f_oar = (w >> 20) & 0x3FFu;
           const bool has_tw = MIXED && f_tw != none;
           if (has_tw) f_oa = f_tw & ~1u;  // s_oa = that HDV's (shifted) record; constrain_adj set below
@@ -1130,22 +1159,16 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD, MIXED>())) void ste
           const int s_ol = gb + (nb.has_ol ? (int)((f_ol >> 1) & 15u) : 0);
           const int s_oa = gb + (nb.has_oa ? (int)((f_oa >> 1) & 15u) : 0);
           const int s_oar = gb + (nb.has_oar ? (int)((f_oar >> 1) & 15u) : 0);
-          nb.ol_x = shfl_d(whx, s_ol); nb.ol_vx = shfl_d(whvx, s_ol);
-          nb.oa_x = shfl_d(whx, s_oa); nb.oa_vx = shfl_d(whvx, s_oa);
-          nb.ol_acc = nb.ol_g = nb.oa_acc = nb.oa_g = 0;
-          if (MASS) {
-            nb.ol_acc = shfl_d(wacc, s_ol); nb.ol_g = shfl_d(wg, s_ol);
-            nb.oa_acc = shfl_d(wacc, s_oa); nb.oa_g = shfl_d(wg, s_oa);
-          }
+          nb.ol_x = shfl_d(whx, s_ol); nb.ol_gu = shfl_d(wgu, s_ol);
+          nb.oa_x = shfl_d(whx, s_oa); nb.oa_gu = shfl_d(wgu, s_oa);
+          nb.ol_vx = nb.oa_vx = nb.ol_acc = nb.ol_g = nb.oa_acc = nb.oa_g = 0;  // folded into ol_gu / oa_gu
           nb.oar_x = shfl_d(wx, s_oar); nb.oar_vx = shfl_d(wvx, s_oar);
           nb.constrain_adj = MASS && nb.has_oa && (f_oa & 1u);
           bool hss_collab = false;
           if (has_tw) { nb.constrain_adj = MASS; hss_collab = !MASS; }  // cbf.constrain_adj = True (:181)
-          if (!nb.has_ol) { nb.ol_acc = 0; nb.ol_g = 0; }
-          if (!nb.has_oa) { nb.oa_acc = 0; nb.oa_g = 0; }
-          if (!MASS) { nb.ol_acc = kCbfAccLo; nb.oa_acc = kCbfAccLo; }
+          // (absent slots contribute g*u = 0, an obstacle +0: handled in shield_dyn<.., PRE> / obstacle_override)
           obstacle_override<MASS>(nb, v.x, v.y);
-          ShieldOut s1 = shield_eval<MASS>(c, v, cpsi, offL, offR, nb);
+          ShieldOut s1 = shield_eval<MASS, true>(c, v, cpsi, offL, offR, nb);
           if (hss_collab) s1.flags |= MM_FLAG_IS_COLLABORATING;  // vehicle.is_collaborating = cbf.constrain_adj
           if (has && a == ai && shield_on) {
             new_acc = s1.acc; veto = s1.veto; new_flags = s1.flags; qt = s1.qt;
@@ -1157,6 +1180,7 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD, MIXED>())) void ste
             // publish my post-step view (Vehicle.step committed) for the later stages
             wx = cc.x; wy = cc.y; wh = cc.h; wg = cc.gvx; wacc = new_acc; wvx = nv * cc.cpsi;
             whx = s_cold[C_H1X][tid]; whvx = s_cold[C_H1VX][tid]; wlane = cc.lane; wnl = cc.nl; woffL = cc.offL; woffR = cc.offR;
+            wgu = slot_gu<MASS>(whvx, MASS ? wacc : kCbfAccLo, wg, dt);
           }
         }
         // the in-place history edits persist in the record that becomes state_hist[-2] (stepped HDV)
