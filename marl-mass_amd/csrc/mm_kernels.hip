@@ -544,7 +544,8 @@ struct ShieldOut {
   double acc, us0;  // derived acceleration, u_safe[0]
   bool veto;        // "Avoiding lane change" (:501-506 / :739-744)
   bool lon_safe, lon_invariant;  // CBF_AV.update_status cbf.py:341-351
-  double headway;                // vehicle.set_min_headway (decentral_layer.py:466,700); trace only
+  double hw_num, hw_den;         // vehicle.set_min_headway = hw_num / hw_den (decentral_layer.py:466,700); the
+                                 // division is left to the trace writer (it is wanted only when tracing)
   int flags;
   QpTrace qt;
 };
@@ -659,7 +660,7 @@ MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s
     const double hlds_lon = s.px_lon + ((-s.g0) * us0 + g2u2) + s.q_lon;
     o.lon_safe = hls_lon >= -1e-6;
     o.lon_invariant = (hlds_lon + (eta - 1) * hls_lon) >= -1e-6;
-    o.headway = (s.px_lon - kVehLength) / s.evx;
+    o.hw_num = s.px_lon - kVehLength; o.hw_den = s.evx;
   }
   // is_lc_allowed (cbf.py:324-339)
   const double hlds_lona = s.px_lona + ((-s.g0) * us0 + g4u4) + s.q_lona;
@@ -727,7 +728,7 @@ MM_DEV Rel relate(double ex, double ey, int elane, int enl, bool other, double o
 MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
   t[MM_T_STATUS * A] = (double)(MM_ST_RAN | MM_ST_IS_OPTIMAL | (o.lon_safe ? MM_ST_IS_SAFE : 0u) |
                                 (o.lon_invariant ? MM_ST_IS_INVARIANT : 0u));
-  t[MM_T_HEADWAY * A] = o.headway;
+  t[MM_T_HEADWAY * A] = o.hw_num / o.hw_den;
 }
 
 // ------------------------------------------------------------------------------------------------
