@@ -737,11 +737,8 @@ MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
 #ifndef MM_MIN_WAVES
 #define MM_MIN_WAVES 2  // 2 waves/SIMD: measured 0.62 ms vs 0.98 (1) / 0.92 (3, spills) at 65536x8 MASS
 #endif
-// The 16-lane groups of the parallel-form kernel (HSS, CAV-only) carry twice the partner state: at
-// 2 waves/SIMD they spill ~1 KB/lane to scratch; with the whole 512-register file (1 wave/SIMD) they run
-// 1.6x faster.  The serial-only kernels (MASS, general) need no spills at 2 waves/SIMD at any G.
 template <int G, int SHIELD, bool MIXED>
-constexpr int step_min_waves() { return (G == 16 && SHIELD == MM_SHIELD_HSS && !MIXED) ? 1 : MM_MIN_WAVES; }
+constexpr int step_min_waves() { return MM_MIN_WAVES; }
 template <int G, int KIND, int SHIELD, bool MIXED>
 __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD, MIXED>())) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
                                                    MMStepOut out, double *metrics) {
@@ -754,7 +751,11 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD, MIXED>())) void ste
   // leaders' decided accelerations costs the parallel form its rounds -- while with HDVs the digital-twin case
   // sent most sub-steps to the fallback anyway (2.30 -> 1.04 ms).  HSS has no such coupling: its parallel
   // form is 14 % faster (0.38 vs 0.44 ms) and is what runs, with the literal sweep as fallback.
-  constexpr bool kSerialOnly = MIXED || MASS;
+#ifdef MM_SERIAL_ALL  // tuning switch: every shielded kernel carries the literal sweep only
+  constexpr bool kSerialOnly = true;
+#else
+  constexpr bool kSerialOnly = MIXED || MASS || G == 16;  // (G = 16 HSS: 0.6x the time of its parallel form)
+#endif
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long e = gtid / G;
   const int a = (int)(gtid % G);
