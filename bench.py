@@ -81,6 +81,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    here = os.path.dirname(os.path.abspath(__file__))
+    if rank == 0 and not os.path.exists(os.path.join(here, "marl-mass_amd", "csrc", "libmm_hip.so")):
+        import __graft_entry__  # fresh checkout: the library is a build artefact
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier(device_ids=[local])
     from marl_mass_amd import VecMergeEnv, reduce_rollout_metrics
     E, N = args.envs, args.agents
     cfg = {"safety_guarantee": SHIELDS[args.shield], "HEADWAY_TIME": 0.5 if args.shield != "none" else 1.2}

@@ -11,6 +11,11 @@ for p in (REPO, os.path.join(REPO, "oracle"), os.path.join(REPO, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the native libraries are build artefacts (git-ignored): build them when a fresh checkout has none
+    need = [os.path.join(REPO, "marl-mass_amd", "csrc", "libmm_hip.so"), os.path.join(REPO, "oracle", "libmm_oracle.so")]
+    if not all(os.path.exists(f) for f in need):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
