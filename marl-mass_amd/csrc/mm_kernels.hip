@@ -737,8 +737,13 @@ MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
 #ifndef MM_MIN_WAVES
 #define MM_MIN_WAVES 2  // 2 waves/SIMD: measured 0.62 ms vs 0.98 (1) / 0.92 (3, spills) at 65536x8 MASS
 #endif
+// Unshielded kernels are small (30 KB LDS, 189 VGPRs unconstrained): at 4 waves/SIMD (128 VGPRs, 128 B/lane
+// of spills) the extra latency hiding wins: 0.247 -> 0.203 ms at 65536 x 8 (3 waves: 0.231, 5: 0.267, 6: 0.240).
+#ifndef MM_NONE_WAVES
+#define MM_NONE_WAVES 4
+#endif
 template <int G, int SHIELD, bool MIXED>
-constexpr int step_min_waves() { return MM_MIN_WAVES; }
+constexpr int step_min_waves() { return (SHIELD == MM_SHIELD_NONE && !MIXED) ? MM_NONE_WAVES : MM_MIN_WAVES; }
 template <int G, int KIND, int SHIELD, bool MIXED>
 __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD, MIXED>())) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
                                                    MMStepOut out, double *metrics) {
@@ -799,7 +804,8 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD, MIXED>())) void ste
   // 100 B/lane of scratch costs ~8 % of the kernel): the LC-veto candidate B, the history records,
   // the previous safe action, the target speed, and the 7..15 sort keys of the classification pass.
   enum { C_B = 0, C_H1X = 7, C_H1VX, C_H2X, C_H2VX, C_SSTEER, C_SACC, C_TSPEED, C_A = 14, kColdB = 21 };
-  constexpr int kColdN = kColdB + (kSerialOnly ? 0 : G - 1);  // the sort keys are a parallel-form temporary
+  // unshielded kernels use only slots 7..13 (+ the obs staging: 15 slots); the sort keys are a parallel-form temporary
+  constexpr int kColdN = !SHIELDED ? 15 : kColdB + (kSerialOnly ? 0 : G - 1);
   static_assert(kColdN * 2048 >= 4 * 64 * 30 * 4, "the obs staging must fit in the cold slots");
   __shared__ double s_cold[kColdN][256];
   const int tid = threadIdx.x;
