@@ -235,3 +235,19 @@ def test_policy_act_hip_mfma(n_s, n):
     assert torch.equal(acts.cpu(), _sample(oracle_env.library(), logp.cpu().contiguous(), 99, c2))
     acts2, _ = _policy_act(hip_library(), obs, actor, 99, ctr, want_logp=False)  # counter advanced: new draw
     assert not torch.equal(acts, acts2) or n < 64
+
+
+def test_interact_fused_policy_path_is_reproducible():
+    """Default path (no torch generator, reference ActorNetwork): DeviceRollout.act is one mm_policy_act call;
+    two rollouts built the same way draw the same actions, and a different sample_seed draws others."""
+    def make(seed):
+        torch.manual_seed(0)
+        env = oracle_env.OracleEnv(16, 4, env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-avs_cint", "HEADWAY_TIME": 0.5},
+                                   cbf_eta=0.03125, cbf_tau=0.5, seed=3, auto_reset=True)
+        ro = DeviceRollout(env, ActorNetwork(30, 128, 5), CriticNetwork(30, 5, 128), roll_out_n_steps=12, sample_seed=seed)
+        assert ro.fused_policy
+        return ro.interact()
+    a, b, c = make(1), make(1), make(2)
+    assert torch.equal(a["actions"], b["actions"]) and torch.equal(a["returns"], b["returns"])
+    assert not torch.equal(a["actions"], c["actions"])
+    assert len(torch.unique(a["actions"])) > 1
