@@ -69,3 +69,44 @@ def test_product_path_refuses_cpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         VecMergeEnv(4, 4)
+
+
+def _create_rc(clib, E, N, device="cpu", **over):
+    """mm_create's status for a given (E, N, config) with a correctly sized state buffer."""
+    import torch
+    cfg = abi.make_config("merge-multi-agent-v1", abi.default_env_config("merge-multi-agent-v1"))
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    lay = abi.MMStateLayout()
+    if clib.lib.mm_state_layout(max(E, 1), min(max(N, 1), 16), ctypes.byref(lay)) != 0:
+        return "layout"
+    buf = torch.zeros(lay.total_bytes + 256, dtype=torch.uint8, device=device)
+    ptr = buf.data_ptr() + (-buf.data_ptr()) % 256
+    h = ctypes.c_void_p()
+    rc = clib.lib.mm_create(ctypes.byref(cfg), E, N, 0, ctypes.c_void_p(ptr), lay.total_bytes, 0, ctypes.byref(h))
+    if rc == 0:
+        clib.lib.mm_destroy(h)
+    return rc
+
+
+def test_create_rejects_bad_sizes_and_configs():
+    """Edge cases of the boundary (oracle build): empty batch, zero / too many vehicles, an HDV count that
+    leaves no controlled vehicle, a foreign ABI version, an unknown shield id -> error codes, not crashes."""
+    import oracle_env
+    clib = oracle_env.library()
+    assert _create_rc(clib, 4, 8) == 0
+    assert _create_rc(clib, 1, 1) == 0 and _create_rc(clib, 3, 12) == 0        # smallest / largest env
+    assert _create_rc(clib, 0, 8) != 0 and _create_rc(clib, -1, 8) != 0         # empty batch
+    assert _create_rc(clib, 4, 0) != 0 and _create_rc(clib, 4, 13) != 0         # beyond the 6 + 6 spawn slots
+    assert _create_rc(clib, 4, 8, n_hdv=8) != 0 and _create_rc(clib, 4, 8, n_hdv=-1) != 0
+    assert _create_rc(clib, 4, 8, abi_version=abi.MM_ABI_VERSION + 1) != 0
+    assert _create_rc(clib, 4, 8, shield=7) != 0
+
+
+@pytest.mark.gpu
+def test_create_rejects_bad_sizes_hip():
+    from marl_mass_amd import hip_library
+    clib = hip_library()
+    assert _create_rc(clib, 4, 8, device="cuda") == 0
+    for E, N, over in ((0, 8, {}), (4, 0, {}), (4, 13, {}), (4, 8, {"n_hdv": 8}), (4, 8, {"abi_version": 1}), (4, 8, {"shield": 9})):
+        assert _create_rc(clib, E, N, device="cuda", **over) != 0, (E, N, over)
