@@ -337,3 +337,37 @@ def test_full_size_properties():
     assert torch.equal(env.f64[:, E // 2:].nan_to_num(), half.f64.nan_to_num()) and torch.equal(env.u8[:, E // 2:], half.u8)
     xs = env.f64[abi.F["X"]]
     assert bool((xs > 0).all()) and bool((env.f64[abi.F["SPEED"]] >= 0).all())
+
+
+@pytest.mark.parametrize("safety,with_hdv", [("cbf-cav", False), ("cbf-avs_cint", False), ("cbf-cav", True), ("none", True)])
+def test_ragged_batch_with_absent_slots(safety, with_hdv):
+    """Envs of ONE batch with different vehicle counts (absent slots = NaN x, as the compat adapter pads a
+    12-slot env): 2..8 vehicles per env, optionally a CAV prefix followed by HDVs, host-provided spawn on
+    both sides, 40 steps, every bit equal to the oracle's."""
+    E, N = 512, 8
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125,
+              cbf_tau=0.5, seed=5, n_hdv=3 if with_hdv else 0)
+    gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
+    cpu.reset()  # a valid spawn to carve the ragged batch from
+    gpu.reset()  # (same counters on both sides)
+    x, y = cpu.f64[abi.F["X"]].clone(), cpu.f64[abi.F["Y"]].clone()
+    h, v = cpu.f64[abi.F["HEADING"]].clone(), cpu.f64[abi.F["SPEED"]].clone()
+    g = torch.Generator().manual_seed(8)
+    count = torch.randint(2, N + 1, (E,), generator=g)
+    slot = torch.arange(N)[None, :]
+    x[slot >= count[:, None]] = float("nan")
+    kind = torch.ones(E, N, dtype=torch.int64)
+    if with_hdv:  # CAVs first, then HDVs: at least one CAV
+        n_cav = torch.maximum(torch.ones_like(count), count - torch.randint(0, 4, (E,), generator=g))
+        kind[slot >= n_cav[:, None]] = 2
+    og, _ = gpu.set_kinematics(x.cuda(), y.cuda(), h.cuda(), v.cuda(), kind=kind.cuda())
+    oc, _ = cpu.set_kinematics(x, y, h, v, kind=kind)
+    assert torch.equal(og.cpu(), oc) and torch.equal(gpu.u8.cpu(), cpu.u8) and torch.equal(gpu.env_i32.cpu(), cpu.env_i32)
+    p = torch.tensor([0.15, 0.5, 0.15, 0.1, 0.1])
+    for t in range(40):
+        a = torch.multinomial(p, E * N, True, generator=g).view(E, N).int()
+        og, rg, dg, ig = gpu.step(a.cuda())
+        oc, rc, dc, ic = cpu.step(a)
+        assert torch.equal(og.cpu(), oc) and torch.equal(rg.cpu(), rc) and torch.equal(dg.cpu(), dc), t
+        assert torch.equal(ig["regional_rewards"].cpu(), ic["regional_rewards"]) and torch.equal(ig["min_headway"].cpu(), ic["min_headway"]), t
+    assert torch.equal(gpu.u8.cpu(), cpu.u8) and torch.equal(gpu.f64.cpu().nan_to_num(), cpu.f64.nan_to_num())
