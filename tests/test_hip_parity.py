@@ -288,7 +288,10 @@ def test_baseline_configs_bit_exact(name, env_id, safety, E, N, eta, tau):
 
 @pytest.mark.parametrize("safety,n_hdv,lateral,N", [("cbf-cav", 0, "steer", 8), ("cbf-avs_cint", 0, "steer", 8), ("cbf-cav", 3, "steer", 8),
                                                       ("cbf-cav", 0, "steer_vel", 8), ("cbf-cav", 0, "steer", 4), ("cbf-cav", 0, "steer", 12),
-                                                      ("cbf-avs_cint", 0, "steer", 2), ("cbf-cav", 5, "steer", 11), ("none", 2, "steer", 4)])
+                                                      ("cbf-avs_cint", 0, "steer", 2), ("cbf-cav", 5, "steer", 11), ("none", 2, "steer", 4),
+                                                      # the parallel-form kernels (HSS, CAV-only, N <= 8) at every ragged size
+                                                      ("cbf-avs_cint", 0, "steer", 3), ("cbf-avs_cint", 0, "steer", 4), ("cbf-avs_cint", 0, "steer", 5),
+                                                      ("cbf-avs_cint", 0, "steer", 6), ("cbf-avs_cint", 0, "steer", 7), ("cbf-avs", 0, "steer", 8)])
 def test_soak_three_episodes_bit_exact(safety, n_hdv, lateral, N):
     """Long free-running soak: 4096 envs x N vehicles x 320 steps (three full episodes with auto-reset),
     checked against the oracle every 40 steps and at the end -- ~10 M agent-steps per case, every bit,
