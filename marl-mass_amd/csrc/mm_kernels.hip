@@ -748,7 +748,10 @@ template <int G, int SHIELD, bool MIXED>
 #endif
 constexpr int step_min_waves() { return SHIELD == MM_SHIELD_NONE ? (MIXED ? MM_GENERAL_NONE_WAVES : MM_NONE_WAVES) : MM_MIN_WAVES; }
 template <int G, int KIND, int SHIELD, bool MIXED>
-__global__ __launch_bounds__(256, (step_min_waves<G, SHIELD, MIXED>())) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
+#ifndef MM_STEP_BLOCK
+#define MM_STEP_BLOCK 256
+#endif
+__global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
                                                    MMStepOut out, double *metrics) {
   constexpr bool LC = (KIND == MM_ENV_V1);
   constexpr bool SHIELDED = LC && (SHIELD != MM_SHIELD_NONE);
@@ -809,8 +812,8 @@ __global__ __launch_bounds__(256, (step_min_waves<G, SHIELD, MIXED>())) void ste
   enum { C_B = 0, C_H1X = 7, C_H1VX, C_H2X, C_H2VX, C_SSTEER, C_SACC, C_TSPEED, C_A = 14, kColdB = 21 };
   // unshielded kernels use only slots 7..13 (+ the obs staging: 15 slots); the sort keys are a parallel-form temporary
   constexpr int kColdN = !SHIELDED ? 15 : kColdB + (kSerialOnly ? 0 : G - 1);
-  static_assert(kColdN * 2048 >= 4 * 64 * 30 * 4, "the obs staging must fit in the cold slots");
-  __shared__ double s_cold[kColdN][256];
+  static_assert(kColdN * MM_STEP_BLOCK * 8 >= (MM_STEP_BLOCK / 64) * 64 * 30 * 4, "the obs staging must fit in the cold slots");
+  __shared__ double s_cold[kColdN][MM_STEP_BLOCK];
   const int tid = threadIdx.x;
   if (LC) {
     s_cold[C_H1X][tid] = v.h1x; s_cold[C_H1VX][tid] = v.h1vx; s_cold[C_H2X][tid] = v.h2x; s_cold[C_H2VX][tid] = v.h2vx;
@@ -1799,8 +1802,8 @@ extern "C" int32_t mm_observe(MMHandle h, void *obs, uint8_t *avail, MMStream st
 template <int G, int KIND, int SHIELD, bool MIXED>
 static void launch_step_t(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   const long long threads = (long long)h->E * G;
-  const unsigned grid = (unsigned)((threads + 255) / 256);
-  hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, MIXED>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h),
+  const unsigned grid = (unsigned)((threads + MM_STEP_BLOCK - 1) / MM_STEP_BLOCK);
+  hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, MIXED>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dev_cfg(h), dev_state(h),
                      actions, *out, h->metrics);
 }
 template <int G, bool MIXED>
