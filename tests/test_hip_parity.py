@@ -374,3 +374,28 @@ def test_ragged_batch_with_absent_slots(safety, with_hdv):
         assert torch.equal(og.cpu(), oc) and torch.equal(rg.cpu(), rc) and torch.equal(dg.cpu(), dc), t
         assert torch.equal(ig["regional_rewards"].cpu(), ic["regional_rewards"]) and torch.equal(ig["min_headway"].cpu(), ic["min_headway"]), t
     assert torch.equal(gpu.u8.cpu(), cpu.u8) and torch.equal(gpu.f64.cpu().nan_to_num(), cpu.f64.nan_to_num())
+
+
+@pytest.mark.parametrize("name", ["ep_v1_mass_N8_s0", "mx_v1_hss_4c3h_s25", "sv_v1_mass_N8_s50"])
+def test_compat_adapter_on_gpu_matches_golden(name):
+    """The drop-in object API (MergeEnvCompat: numpy-RNG reset replay + step tuple + control profile) over the
+    HIP backend, free-running on a reference tape: what a maintainer's `env = make(env_id)` swap executes."""
+    from marl_mass_amd import compat
+    from golden_util import GOLDEN
+    z, meta = load_episode(os.path.join(GOLDEN, name + ".npz"))
+    compat.CBFType.GAMMA_B, compat.CBFType.TAU = meta["eta"], meta["headway_time"]
+    env = compat.make(meta["env_id"], store_profile=True)
+    env.config.update({"safety_guarantee": meta["shield"], "HEADWAY_TIME": meta["headway_time"], "action_masking": False,
+                       "lateral_control": meta.get("lateral_control", "steer")})
+    env._num_vehicles = lambda num_CAV=0: (meta["n"], meta.get("n_hdv", 0))
+    obs, avail = env.reset(is_training=False, testing_seeds=meta["seed"])
+    np.testing.assert_allclose(obs, z["obs0"], rtol=0, atol=1e-12)
+    for t in range(meta["steps"]):
+        obs, reward, done, info = env.step(tuple(int(a) for a in z["actions"][t]))
+        np.testing.assert_allclose(obs, z["obs"][t], rtol=0, atol=1e-9)
+        assert abs(reward - z["reward"][t]) <= 1e-9 and done == bool(z["done"][t])
+        np.testing.assert_allclose(info["regional_rewards"], z["regional_rewards"][t], rtol=0, atol=1e-9)
+    assert done and env.is_crashed() == meta["crashed"]
+    cp = env.control_profile()
+    assert len(cp["av0"]["state_hist"]) == int(z["sub_count"].sum())
+    assert abs(cp["av0"]["state_hist"][-1]["x"] - z["sub_f"][-1][0][0]) <= 1e-9
