@@ -161,17 +161,17 @@ class DeviceRollout(object):
         env, T = self.env, self.T
         E, N, S = self.obs.shape
         dev = self.obs.device
-        states = torch.empty(T, E, N, S, dtype=self.obs.dtype, device=dev)
+        states = torch.empty(T + 1, E, N, S, dtype=self.obs.dtype, device=dev)  # slot t + 1 is written by step t itself
         actions = torch.empty(T, E, N, dtype=torch.int32, device=dev)
         rewards = torch.empty(T, E, N, dtype=torch.float64, device=dev)
         dones = torch.empty(T, E, dtype=torch.uint8, device=dev)
         speed_sum = torch.zeros(E, dtype=torch.float64, device=dev)
         min_headway = torch.full((E,), float("inf"), dtype=torch.float64, device=dev)
-        obs = self.obs
+        states[0] = self.obs
+        obs = states[0]
         for t in range(T):
-            states[t] = obs
             a = self.act(obs)
-            obs, global_reward, done, info = env.step(a)
+            obs, global_reward, done, info = env.step(a, obs_out=states[t + 1])
             actions[t] = a
             rewards[t] = info["regional_rewards"] if self.reward_type == "regionalR" else global_reward.unsqueeze(-1).expand(E, N)
             dones[t] = done
@@ -189,7 +189,7 @@ class DeviceRollout(object):
         if self.reward_scale > 0:
             rewards = rewards / self.reward_scale  # :152-153
         returns = discount_rewards(rewards, dones, final_value, self.gamma)
-        return {"states": states, "actions": actions, "returns": returns, "dones": dones,
+        return {"states": states[:T], "actions": actions, "returns": returns, "dones": dones,
                 "average_speed": speed_sum / T, "min_headway": min_headway}
 
     @torch.no_grad()

@@ -145,14 +145,25 @@ class BatchedMergeEnv(object):
                                                  self._stream()), self._h)
         return self.obs, self.avail
 
-    def step(self, actions):
-        """MergeEnv.step (merge_env_v1.py:126-166) for every env; actions int32 [E, N] in 0..4."""
+    def step(self, actions, obs_out=None):
+        """MergeEnv.step (merge_env_v1.py:126-166) for every env; actions int32 [E, N] in 0..4.
+        obs_out: optional caller buffer (same shape / dtype / device as self.obs, contiguous) the new
+        observation is written to instead of self.obs -- a rollout hands over its states[t + 1] slot."""
         if actions.dtype != torch.int32 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(self.device, torch.int32).contiguous()
         assert actions.numel() == self.E * self.N
-        self.clib.check(self.clib.lib.mm_step(self._h, _ptr(actions), C.byref(self._step_out),
-                                              self._stream()), self._h)
-        return self.obs, self.out["reward"], self.out["done"], self.out
+        obs = self.obs
+        if obs_out is not None:
+            assert obs_out.shape == self.obs.shape and obs_out.dtype == self.obs.dtype and obs_out.device == self.obs.device \
+                and obs_out.is_contiguous()
+            obs = obs_out
+            self._step_out.obs = obs.data_ptr()
+        try:
+            self.clib.check(self.clib.lib.mm_step(self._h, _ptr(actions), C.byref(self._step_out),
+                                                  self._stream()), self._h)
+        finally:
+            self._step_out.obs = self.obs.data_ptr()
+        return obs, self.out["reward"], self.out["done"], self.out
 
     def enable_metrics(self):
         """Device-side rollout metric accumulator: 7 sums + 1 min."""
