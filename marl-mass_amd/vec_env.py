@@ -165,6 +165,25 @@ class BatchedMergeEnv(object):
             self._step_out.obs = self.obs.data_ptr()
         return obs, self.out["reward"], self.out["done"], self.out
 
+    # -- checkpoint / resume --------------------------------------------------------------
+    def state_dict(self):
+        """Everything an env batch needs to resume bit-identically: the caller-owned state buffer (all planes,
+        counters, per-env RNG seeds) and the last observation.  Config is the constructor's business."""
+        d = {"abi_version": abi.MM_ABI_VERSION, "E": self.E, "N": self.N, "env_id": self.env_id,
+             "state": self.state.clone(), "obs": self.obs.clone(), "avail": self.avail.clone()}
+        if self.metrics is not None:
+            d["metrics"] = self.metrics.clone()
+        return d
+
+    def load_state_dict(self, d):
+        if (d["abi_version"], d["E"], d["N"], d["env_id"]) != (abi.MM_ABI_VERSION, self.E, self.N, self.env_id):
+            raise ValueError("checkpoint is for a different batch shape / env / ABI version")
+        self.state.copy_(d["state"].to(self.device))
+        self.obs.copy_(d["obs"].to(self.device))
+        self.avail.copy_(d["avail"].to(self.device))
+        if "metrics" in d and self.metrics is not None:
+            self.metrics.copy_(d["metrics"].to(self.device))
+
     def enable_metrics(self):
         """Device-side rollout metric accumulator: 7 sums + 1 min."""
         self.metrics = torch.zeros(8, dtype=torch.float64, device=self.device)

@@ -74,3 +74,28 @@ def test_shard_range_covers_batch():
         got = [shard_range(total, r, world) for r in range(world)]
         assert sum(c for _, c in got) == total
         assert all(got[i][0] + got[i][1] == got[i + 1][0] for i in range(world - 1))
+
+
+def test_checkpoint_resume_is_bit_identical():
+    """state_dict / load_state_dict of an env batch (oracle backend): resume reproduces the continuation."""
+    import torch
+    import oracle_env
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125,
+              cbf_tau=0.5, seed=12, auto_reset=True, n_hdv=2)
+    env = oracle_env.OracleEnv(32, 6, **kw)
+    env.reset()
+    g = torch.Generator().manual_seed(0)
+    acts = [torch.randint(0, 5, (32, 6), generator=g, dtype=torch.int32) for _ in range(30)]
+    for a in acts[:10]:
+        env.step(a)
+    ck = env.state_dict()
+    ref = [tuple(t.clone() for t in env.step(a)[:3]) for a in acts[10:]]
+    fresh = oracle_env.OracleEnv(32, 6, **kw)
+    fresh.load_state_dict(ck)
+    for a, (o, r, d) in zip(acts[10:], ref):
+        o2, r2, d2, _ = fresh.step(a)
+        assert torch.equal(o2, o) and torch.equal(r2, r) and torch.equal(d2, d)
+    assert torch.equal(fresh.state, env.state)
+    import pytest
+    with pytest.raises(ValueError):
+        oracle_env.OracleEnv(16, 6, **kw).load_state_dict(ck)
