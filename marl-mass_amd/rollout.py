@@ -97,6 +97,17 @@ class DeviceRollout(object):
                 raise ValueError("use_graph samples from the default CUDA generator (captured Philox offset)")
         self._graph, self._static = None, None
 
+    def state_dict(self):
+        """Resume point of a rollout stream: env batch + carried observation + sampler counter."""
+        return {"env": self.env.state_dict(), "obs": self.obs.clone(), "sample_counter": self._sample_counter.clone(),
+                "sample_seed": self.sample_seed}
+
+    def load_state_dict(self, d):
+        self.env.load_state_dict(d["env"])
+        self.obs.copy_(d["obs"].to(self.obs.device))
+        self._sample_counter.copy_(d["sample_counter"].to(self._sample_counter.device))
+        self.sample_seed = int(d["sample_seed"])
+
     @torch.no_grad()
     def act(self, obs):
         """exploration_action / action (marl/mappo.py:220-236): sample from softmax(actor(obs))."""

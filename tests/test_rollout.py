@@ -251,3 +251,21 @@ def test_interact_fused_policy_path_is_reproducible():
     assert torch.equal(a["actions"], b["actions"]) and torch.equal(a["returns"], b["returns"])
     assert not torch.equal(a["actions"], c["actions"])
     assert len(torch.unique(a["actions"])) > 1
+
+
+def test_rollout_checkpoint_resume():
+    """DeviceRollout.state_dict / load_state_dict: the resumed stream draws the same actions and returns."""
+    def make():
+        torch.manual_seed(0)
+        env = oracle_env.OracleEnv(8, 4, env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
+                                   cbf_eta=0.03125, cbf_tau=0.5, seed=3, auto_reset=True)
+        return DeviceRollout(env, ActorNetwork(30, 128, 5), CriticNetwork(30, 5, 128), roll_out_n_steps=7, sample_seed=5)
+    a = make()
+    a.interact()
+    ck = a.state_dict()
+    ref = a.interact()
+    b = make()
+    b.load_state_dict(ck)
+    out = b.interact()
+    for k in ("states", "actions", "returns", "dones"):
+        assert torch.equal(out[k], ref[k]), k
