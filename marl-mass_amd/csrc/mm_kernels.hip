@@ -765,7 +765,11 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
 #ifdef MM_SERIAL_ALL  // tuning switch: every shielded kernel carries the literal sweep only
   constexpr bool kSerialOnly = true;
 #else
-  constexpr bool kSerialOnly = MIXED || MASS || G == 16;  // (G = 16 HSS: 0.6x the time of its parallel form)
+#ifdef MM_SERIAL_MASS  // tuning switch: MASS in the literal form at every size
+  constexpr bool kSerialOnly = MIXED || MASS;
+#else
+  constexpr bool kSerialOnly = MIXED;
+#endif
 #endif
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long e = gtid / G;
@@ -809,9 +813,10 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   // slots, one column per thread) instead of being spilled to scratch by the compiler (measured: each
   // 100 B/lane of scratch costs ~8 % of the kernel): the LC-veto candidate B, the history records,
   // the previous safe action, the target speed, and the 7..15 sort keys of the classification pass.
-  enum { C_B = 0, C_H1X = 7, C_H1VX, C_H2X, C_H2VX, C_SSTEER, C_SACC, C_TSPEED, C_A = 14, kColdB = 21 };
+  // (C_GU0 / C_GU1: parallel form only -- the g*u product of my pre- / post-step record for the askers' gather)
+  enum { C_B = 0, C_H1X = 7, C_H1VX, C_H2X, C_H2VX, C_SSTEER, C_SACC, C_TSPEED, C_A = 14, C_GU0 = 21, C_GU1 = 22, kColdB = 23 };
   // unshielded kernels use only slots 7..13 (+ the obs staging: 15 slots); the sort keys are a parallel-form temporary
-  constexpr int kColdN = !SHIELDED ? 15 : kColdB + (kSerialOnly ? 0 : G - 1);
+  constexpr int kColdN = !SHIELDED ? 15 : (kSerialOnly ? 21 : kColdB + G - 1);
   static_assert(kColdN * MM_STEP_BLOCK * 8 >= (MM_STEP_BLOCK / 64) * 64 * 30 * 4, "the obs staging must fit in the cold slots");
   __shared__ double s_cold[kColdN][MM_STEP_BLOCK];
   const int tid = threadIdx.x;
@@ -987,58 +992,47 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         // DECIDED acceleration -> fixed point over the leader chain, (2) a veto changes what
         // later vehicles see -> outer fixed point.  Both iterate to the unique sequential answer
         // (induction on rank: the rank-r vehicle is final after r+1 rounds / passes).
+        // Register discipline: the partner loop only classifies and selects (key, index, flags) per slot;
+        // the chosen neighbours' records are gathered afterwards from their owners' LDS columns (the history
+        // records already live there, the g*u products are parked at the top of the pass), so the loop does
+        // not drag 10 neighbour fields and their select chains through 7 (15) partners.
+        static_assert(!MIXED || kSerialOnly, "the parallel form is CAV-only (the twin branch needs the literal sweep)");
         bool irregular = false;
         for (int pass = 0; pass <= st.N; pass++) {
           const Cand mine = chosen(use_B);
-          // what I show to a partner: post-state if I step before it, else pre-state
+          const double h1vx_mine = s_cold[C_H1VX][tid];
+          s_cold[C_GU0][tid] = slot_gu<MASS>(s_cold[C_H2VX][tid], MASS ? s_cold[C_SACC][tid] : kCbfAccLo, v.gvx, dt);
+          s_cold[C_GU1][tid] = slot_gu<MASS>(h1vx_mine, kCbfAccLo, mine.gvx, dt);  // (MASS: the rounds exchange the live value)
           double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
           int j_ol = -1, j_oa = -1, j_oar = -1;
-          Neigh nb;
-          memset(&nb, 0, sizeof nb);
-          bool ol_dyn = false, oa_dyn = false, oar_stepped = false;
+          bool ol_first = false, oa_first = false, oar_stepped = false, cadj = false;
           for_partners<G>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
             const int p = a ^ m;
             const int p_rank = dppx_i<m>(live ? rank : 99);
             const bool i_first = live && rank < p_rank;  // I step before this partner
-            // message: my state as that partner sees it
+            // message: my pose as that partner sees it (post-state if I step before it, else pre-state)
             const double sx_ = i_first ? mine.x : v.x, sy_ = i_first ? mine.y : v.y, sh_ = i_first ? mine.h : v.h;
             const int spk = i_first ? (mine.lane | mine.nl << 3 | (int)mine.offL << 6 | (int)mine.offR << 7)
                                     : (v.lane | nl_self << 3 | (int)offL << 6 | (int)offR << 7);
-            const double shx = s_cold[i_first ? C_H1X : C_H2X][tid], shvx = s_cold[i_first ? C_H1VX : C_H2VX][tid];  // my state_hist[-2] as seen then
-            // an HDV has no safe_action / fg_params: followers assume (0, -12.5) and g.vx = 1 (:129-135,:205-211)
-            const double sg = hdv ? 1.0 : (i_first ? mine.gvx : v.gvx);
-            const double sacc = hdv ? kCbfAccLo : s_cold[C_SACC][tid];  // my previous decision (read only if I have not stepped)
-            const double svx = v.v * cpsi;    // my current vx (rear-adjacent slot reads to_dict())
             const double ox = dppx_d<m>(sx_), oy = dppx_d<m>(sy_), oh = dppx_d<m>(sh_);
-            const int opk = dppx_i<m>(spk | (int)live << 8 | (int)hdv << 9);
-            const double ohx = dppx_d<m>(shx), ohvx = dppx_d<m>(shvx), og = dppx_d<m>(sg);
-            const double oacc = dppx_d<m>(sacc), ovx = dppx_d<m>(svx);
-            const bool o_hdv = MIXED && ((opk >> 9) & 1) != 0;
-            // partner steps before me (ranks are distinct); an HDV's "decision" is the static worst case
-            const bool o_first = !i_first && p_rank < 99 && !o_hdv;
+            const int opk = dppx_i<m>(spk | (int)live << 8);
+            const bool o_first = !i_first && p_rank < 99;  // partner steps before me (ranks are distinct)
             const Rel r = relate(v.x, v.y, v.lane, nl_self, ((opk >> 8) & 1) != 0, ox, oy, oh, opk & 7, (opk >> 3) & 7,
-                                 ((opk >> 6) & 1) != 0, ((opk >> 7) & 1) != 0, o_hdv);
+                                 ((opk >> 6) & 1) != 0, ((opk >> 7) & 1) != 0);
             s_cold[kColdB + m - 1][tid] = r.key;
-            // the on-ramp HDV "digital twin" edits the HDV's history record in place (:175-180), which
-            // later egos of the sub-step read: an order dependence only the literal sweep reproduces
-            if (MIXED && r.cls == 4) irregular = irregular || shield_on;
             // running "first in sorted order" per class: smaller key, ties by creation index (selects, no branches)
             const bool b_ol = (r.cls == 1) & ((r.key < k_ol) | ((r.key == k_ol) & (p < j_ol)));
             const bool b_oa = (r.cls == 2) & ((r.key < k_oa) | ((r.key == k_oa) & (p < j_oa)));
             const bool b_oar = (r.cls == 3) & ((r.key < k_oar) | ((r.key == k_oar) & (p < j_oar)));
-            k_ol = b_ol ? r.key : k_ol; j_ol = b_ol ? p : j_ol;
-            nb.ol_x = b_ol ? ohx : nb.ol_x; nb.ol_vx = b_ol ? ohvx : nb.ol_vx;
-            nb.ol_g = b_ol ? og : nb.ol_g; nb.ol_acc = b_ol ? oacc : nb.ol_acc; ol_dyn = b_ol ? o_first : ol_dyn;
-            k_oa = b_oa ? r.key : k_oa; j_oa = b_oa ? p : j_oa;
-            nb.oa_x = b_oa ? ohx : nb.oa_x; nb.oa_vx = b_oa ? ohvx : nb.oa_vx;
-            nb.oa_g = b_oa ? og : nb.oa_g; nb.oa_acc = b_oa ? oacc : nb.oa_acc; oa_dyn = b_oa ? o_first : oa_dyn;
-            nb.constrain_adj = b_oa ? r.cflag : nb.constrain_adj;
-            k_oar = b_oar ? r.key : k_oar; j_oar = b_oar ? p : j_oar;
-            nb.oar_x = b_oar ? ox : nb.oar_x; nb.oar_vx = b_oar ? ovx : nb.oar_vx;
-            oar_stepped = b_oar ? ((!i_first) & (p_rank < 99)) : oar_stepped;
+            k_ol = b_ol ? r.key : k_ol; j_ol = b_ol ? p : j_ol; ol_first = b_ol ? o_first : ol_first;
+            k_oa = b_oa ? r.key : k_oa; j_oa = b_oa ? p : j_oa; oa_first = b_oa ? o_first : oa_first;
+            cadj = b_oa ? r.cflag : cadj;
+            k_oar = b_oar ? r.key : k_oar; j_oar = b_oar ? p : j_oar; oar_stepped = b_oar ? o_first : oar_stepped;
           });
           STAMP(3);  // S1 partner classification
+          Neigh nb;
+          memset(&nb, 0, sizeof nb);
           // count = 5 of close_vehicles_to: a slot exists only if its vehicle is among the 5 nearest
           {
             int pos_ol = 0, pos_oa = 0, pos_oar = 0;
@@ -1054,10 +1048,19 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
             nb.has_oa = j_oa >= 0 && pos_oa < 5;
             nb.has_oar = j_oar >= 0 && pos_oar < 5;
           }
-          nb.constrain_adj = MASS && nb.has_oa && nb.constrain_adj;
-          if (!nb.has_ol) { nb.ol_acc = 0; nb.ol_g = 0; ol_dyn = false; }  // defaults a_ol / gp["ol"] (:93-95)
-          if (!nb.has_oa) { nb.oa_acc = 0; nb.oa_g = 0; oa_dyn = false; }
-          if (!MASS) { nb.ol_acc = kCbfAccLo; nb.oa_acc = kCbfAccLo; ol_dyn = oa_dyn = false; }  // worst case :473
+          nb.constrain_adj = MASS && nb.has_oa && cadj;
+          // gather the chosen neighbours' records from their owners' columns (same wave: program order + a
+          // wave-level fence make the parked values visible)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const int t_ol = tid - a + (j_ol < 0 ? a : j_ol), t_oa = tid - a + (j_oa < 0 ? a : j_oa);
+          nb.ol_x = s_cold[ol_first ? C_H1X : C_H2X][t_ol]; nb.ol_gu = s_cold[ol_first ? C_GU1 : C_GU0][t_ol];
+          nb.oa_x = s_cold[oa_first ? C_H1X : C_H2X][t_oa]; nb.oa_gu = s_cold[oa_first ? C_GU1 : C_GU0][t_oa];
+          const int src_ol = gb + (j_ol < 0 ? 0 : j_ol), src_oa = gb + (j_oa < 0 ? 0 : j_oa), src_oar = gb + (j_oar < 0 ? 0 : j_oar);
+          nb.oar_x = shfl_d(v.x, src_oar); nb.oar_vx = shfl_d(v.v * cpsi, src_oar);  // rear adjacent: its current to_dict()
+          // MASS: a neighbour that has stepped shows the acceleration it DECIDED this sub-step -> rounds below
+          bool ol_dyn = MASS && nb.has_ol && ol_first, oa_dyn = MASS && nb.has_oa && oa_first;
           {
             unsigned rep = obstacle_override<MASS>(nb, v.x, v.y);  // the obstacle's action is static
             if (rep & 1u) ol_dyn = false;
@@ -1067,16 +1070,16 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           // a vehicle moves backwards in x; handled by the serial form below
           irregular = irregular || (shield_on && nb.has_oar && oar_stepped);
           // ---- MASS: fixed point over the decided accelerations (HSS: one evaluation) ----------
-          const int src_ol = gb + (j_ol < 0 ? 0 : j_ol), src_oa = gb + (j_oa < 0 ? 0 : j_oa);
           double acc_cur = shield_on ? 0.0 : v.act_acc;  // vehicles without a shield keep their command
           const ShieldStatic ss = shield_static<MASS>(c, v, cpsi, offL, offR, nb);
           for (int round = 0; round <= st.N; round++) {
             if (MASS) {
-              const double da = shfl_d(acc_cur, src_ol), db = shfl_d(acc_cur, src_oa);
-              if (ol_dyn) nb.ol_acc = da;
-              if (oa_dyn) nb.oa_acc = db;
+              const double gu_cur = slot_gu<true>(h1vx_mine, acc_cur, mine.gvx, dt);  // my post-step record under my current decision
+              const double da = shfl_d(gu_cur, src_ol), db = shfl_d(gu_cur, src_oa);
+              if (ol_dyn) nb.ol_gu = da;
+              if (oa_dyn) nb.oa_gu = db;
             }
-            so = shield_dyn<MASS>(c, v, ss, nb);
+            so = shield_dyn<MASS, true>(c, v, ss, nb);
             const double acc_next = shield_on ? so.acc : v.act_acc;
             const bool changed = __double_as_longlong(acc_next) != __double_as_longlong(acc_cur);
             acc_cur = acc_next;
