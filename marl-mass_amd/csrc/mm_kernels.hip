@@ -1005,7 +1005,6 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           s_cold[C_GU1][tid] = slot_gu<MASS>(h1vx_mine, kCbfAccLo, mine.gvx, dt);  // (MASS: the rounds exchange the live value)
           double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
           int j_ol = -1, j_oa = -1, j_oar = -1;
-          bool ol_first = false, oa_first = false, oar_stepped = false, cadj = false;
           for_partners<G>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
             const int p = a ^ m;
@@ -1022,14 +1021,19 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
                                  ((opk >> 6) & 1) != 0, ((opk >> 7) & 1) != 0);
             s_cold[kColdB + m - 1][tid] = r.key;
             // running "first in sorted order" per class: smaller key, ties by creation index (selects, no branches)
-            const bool b_ol = (r.cls == 1) & ((r.key < k_ol) | ((r.key == k_ol) & (p < j_ol)));
-            const bool b_oa = (r.cls == 2) & ((r.key < k_oa) | ((r.key == k_oa) & (p < j_oa)));
-            const bool b_oar = (r.cls == 3) & ((r.key < k_oar) | ((r.key == k_oar) & (p < j_oar)));
-            k_ol = b_ol ? r.key : k_ol; j_ol = b_ol ? p : j_ol; ol_first = b_ol ? o_first : ol_first;
-            k_oa = b_oa ? r.key : k_oa; j_oa = b_oa ? p : j_oa; oa_first = b_oa ? o_first : oa_first;
-            cadj = b_oa ? r.cflag : cadj;
-            k_oar = b_oar ? r.key : k_oar; j_oar = b_oar ? p : j_oar; oar_stepped = b_oar ? o_first : oar_stepped;
+            // (the slot's flags ride in the index word -- bit 4: that partner steps before me, bit 5: its corner
+            // flag -- instead of living as lane masks through the loop: 84 fewer SGPR spills)
+            const bool b_ol = (r.cls == 1) & ((r.key < k_ol) | ((r.key == k_ol) & (p < (j_ol & 15))));
+            const bool b_oa = (r.cls == 2) & ((r.key < k_oa) | ((r.key == k_oa) & (p < (j_oa & 15))));
+            const bool b_oar = (r.cls == 3) & ((r.key < k_oar) | ((r.key == k_oar) & (p < (j_oar & 15))));
+            const int pf = p | (o_first ? 16 : 0) | (r.cflag ? 32 : 0);
+            k_ol = b_ol ? r.key : k_ol; j_ol = b_ol ? pf : j_ol;
+            k_oa = b_oa ? r.key : k_oa; j_oa = b_oa ? pf : j_oa;
+            k_oar = b_oar ? r.key : k_oar; j_oar = b_oar ? pf : j_oar;
           });
+          const bool ol_first = j_ol >= 0 && (j_ol & 16), oa_first = j_oa >= 0 && (j_oa & 16), oar_stepped = j_oar >= 0 && (j_oar & 16);
+          const bool cadj = j_oa >= 0 && (j_oa & 32);
+          j_ol = j_ol < 0 ? -1 : (j_ol & 15); j_oa = j_oa < 0 ? -1 : (j_oa & 15); j_oar = j_oar < 0 ? -1 : (j_oar & 15);
           STAMP(3);  // S1 partner classification
           Neigh nb;
           memset(&nb, 0, sizeof nb);
