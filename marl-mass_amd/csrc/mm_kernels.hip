@@ -233,7 +233,8 @@ MM_DEV void clip_actions(Veh &v, bool lc_vehicle) {
 }
 
 // controller.py:257-267 get_corner("L"/"R") + lane.on_lane of those corners on `lane`
-MM_DEV void corner_flags(double x, double y, double h, int lane, bool &offL, bool &offR) {
+// -> bit0: the front-left corner is off `lane`, bit1: the front-right one
+MM_DEV int corner_flags(double x, double y, double h, int lane) {
   double cx = x + (kCornerLen * mmm_cos(kCornerAlpha + h));
   double cyL = y - (kCornerLen * mmm_sin(kCornerAlpha + h)) + 0.01;
   double cyR = y - (kCornerLen * mmm_sin(-kCornerAlpha + h)) + 0.01;
@@ -242,16 +243,19 @@ MM_DEV void corner_flags(double x, double y, double h, int lane, bool &offL, boo
   bool lon = (-kVehLength <= s && s < lane_len(lane) + kVehLength);
   double rL = cyL - lane_sy(lane), rR = cyR - lane_sy(lane);
   if (lane == MM_LANE_KB0) { rL = rL - off; rR = rR - off; }
-  offL = !(fabs(rL) <= kLaneWidth / 2 + 0 && lon);
-  offR = !(fabs(rR) <= kLaneWidth / 2 + 0 && lon);
+  return (!(fabs(rL) <= kLaneWidth / 2 + 0 && lon) ? 1 : 0) | (!(fabs(rR) <= kLaneWidth / 2 + 0 && lon) ? 2 : 0);
 }
+// "pose code" of a (pre- or post-step) pose as the shield reads it: closest lane | its next_lane << 3 |
+// corner bits << 6.  Kept packed in one VGPR end to end (messages, LDS park, classification) instead of
+// two ints and two lane masks.
+MM_DEV int pose_code(int lane, int nl, int off) { return lane | nl << 3 | off << 6; }
 
 // Predicted post-state of Vehicle.step for a given steering (kinematics.py:122-141,
 // safe_controller.py:151-172): everything that does not depend on the acceleration.
 struct Cand {
   double x, y, h, gvx, cpsi;
-  int lane, nl;  // closest lane of the post-state and its next_lane
-  bool offL, offR;
+  int lane;  // closest lane of the post-state
+  int pk;    // its pose code (SHIELDED only)
 };
 template <int KIND, bool SHIELDED>
 MM_DEV Cand predict(const Veh &v, double steer, double dt, bool sv = false) {
@@ -267,12 +271,8 @@ MM_DEV Cand predict(const Veh &v, double steer, double dt, bool sv = false) {
   c.gvx = (KIND == MM_ENV_V1) ? mmm_cos(c.h + beta) : 0.0;
   c.lane = closest_lane(c.x, c.y, c.h);  // on_state_update kinematics.py:154-159
   c.cpsi = (KIND == MM_ENV_V1) ? mmm_cos(c.h) : 0.0;
-  c.offL = c.offR = false;
-  c.nl = 0;
-  if (SHIELDED) {
-    corner_flags(c.x, c.y, c.h, c.lane, c.offL, c.offR);
-    c.nl = next_lane(c.lane, c.x, c.y);
-  }
+  c.pk = c.lane;
+  if (SHIELDED) c.pk = pose_code(c.lane, next_lane(c.lane, c.x, c.y), corner_flags(c.x, c.y, c.h, c.lane));
   return c;
 }
 
@@ -577,7 +577,7 @@ struct ShieldStatic {
   bool cadj, can_abort_lc;
 };
 template <bool MASS>
-MM_DEV ShieldStatic shield_static(const DevCfg &c, const Veh &v, double cpsi, bool offL, bool offR, const Neigh &nb) {
+MM_DEV ShieldStatic shield_static(const DevCfg &c, const Veh &v, double cpsi, int pk_self, const Neigh &nb) {
   const double dt = c.dt, eta = c.eta;
   ShieldStatic s;
   s.v_min = v.v + kLcMinAcc * dt;
@@ -615,7 +615,7 @@ MM_DEV ShieldStatic shield_static(const DevCfg &c, const Veh &v, double cpsi, bo
   s.h2 = -s.v_min + s.u0;
   s.hls_lona = s.px_lona + s.q_lona;
   s.hls_lonr = s.px_lonr + s.q_lonr;
-  s.can_abort_lc = !offL && !offR;  // :728-736 on the pre-step pose
+  s.can_abort_lc = (pk_self >> 6) == 0;  // neither front corner off the lane (:728-736, pre-step pose)
   return s;
 }
 // The neighbours' predicted speed u = max(0, vx + acc dt) and its CBF-row product (g dt) u, from one record.
@@ -686,8 +686,8 @@ MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s
   return o;
 }
 template <bool MASS, bool PRE = false>
-MM_DEV ShieldOut shield_eval(const DevCfg &c, const Veh &v, double cpsi, bool offL, bool offR, const Neigh &nb) {
-  const ShieldStatic s = shield_static<MASS>(c, v, cpsi, offL, offR, nb);
+MM_DEV ShieldOut shield_eval(const DevCfg &c, const Veh &v, double cpsi, int pk_self, const Neigh &nb) {
+  const ShieldStatic s = shield_static<MASS>(c, v, cpsi, pk_self, nb);
   return shield_dyn<MASS, PRE>(c, v, s, nb);
 }
 
@@ -699,8 +699,8 @@ struct Rel {
   int cls;
   bool cflag;
 };
-MM_DEV Rel relate(double ex, double ey, int elane, int enl, bool other, double ox, double oy, double oh, int olane,
-                  int onl, bool ooffL, bool ooffR, bool o_hdv = false) {
+MM_DEV Rel relate(double ex, double ey, int epk, bool other, double ox, double oy, double oh, int opk, bool o_hdv = false) {
+  const int elane = epk & 7, enl = (epk >> 3) & 7, olane = opk & 7, onl = (opk >> 3) & 7;
   // written with non-short-circuit logic on purpose: it runs once per (ego, partner) pair and should
   // compile to compares and selects, not to exec-mask branches
   Rel r;
@@ -719,7 +719,7 @@ MM_DEV Rel relate(double ex, double ey, int elane, int enl, bool other, double o
   const bool lead = (!adj) & (!twin) & (same | appr) & (ld > 0);
   const int cls = adj ? ((ld < 0) ? 3 : 2) : (twin ? 4 : (lead ? 1 : 0));
   r.cls = close ? cls : 0;
-  r.cflag = ((v_a == -1) | (a_v == 1)) ? ooffL : ooffR;  // :146-152 which front corner of `o`
+  r.cflag = ((opk >> (((v_a == -1) | (a_v == 1)) ? 6 : 7)) & 1) != 0;  // :146-152 which front corner of `o`
   return r;
 }
 
@@ -802,12 +802,8 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
 
   // derived per-vehicle registers the shield keeps current across sub-steps
   double cpsi = ((SHIELDED || MIXED) && v.present) ? mmm_cos(v.h) : 1.0;
-  bool offL = false, offR = false;
-  int nl_self = 0;
-  if (SHIELDED && v.present) {
-    corner_flags(v.x, v.y, v.h, v.lane, offL, offR);
-    nl_self = next_lane(v.lane, v.x, v.y);
-  }
+  int pk_self = v.lane;  // pose code of my current (pre-step) pose
+  if (SHIELDED && v.present) pk_self = pose_code(v.lane, next_lane(v.lane, v.x, v.y), corner_flags(v.x, v.y, v.h, v.lane));
 
   // Register relief: lane-private values that are written once and read rarely live in LDS ("cold"
   // slots, one column per thread) instead of being spilled to scratch by the compiler (measured: each
@@ -943,7 +939,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     auto park = [&](int base, const Cand &cc, double steer) {  // a candidate's LDS image
       s_cold[base + 0][tid] = cc.x; s_cold[base + 1][tid] = cc.y; s_cold[base + 2][tid] = cc.h;
       s_cold[base + 3][tid] = cc.gvx; s_cold[base + 4][tid] = cc.cpsi; s_cold[base + 5][tid] = steer;
-      s_cold[base + 6][tid] = (double)(cc.lane | cc.nl << 3 | (int)cc.offL << 6 | (int)cc.offR << 7);
+      s_cold[base + 6][tid] = (double)cc.pk;
     };
     if (SHIELDED) park(C_A, cA, v.act_steer);
     STAMP(2);  // predict A
@@ -970,7 +966,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
       cc.x = s_cold[base + 0][tid]; cc.y = s_cold[base + 1][tid]; cc.h = s_cold[base + 2][tid];
       cc.gvx = s_cold[base + 3][tid]; cc.cpsi = s_cold[base + 4][tid];
       const int pk = (int)s_cold[base + 6][tid];
-      cc.lane = pk & 7; cc.nl = (pk >> 3) & 7; cc.offL = ((pk >> 6) & 1) != 0; cc.offR = ((pk >> 7) & 1) != 0;
+      cc.pk = pk; cc.lane = pk & 7;
       return cc;
     };
     double new_acc = v.act_acc;
@@ -1012,13 +1008,11 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
             const bool i_first = live && rank < p_rank;  // I step before this partner
             // message: my pose as that partner sees it (post-state if I step before it, else pre-state)
             const double sx_ = i_first ? mine.x : v.x, sy_ = i_first ? mine.y : v.y, sh_ = i_first ? mine.h : v.h;
-            const int spk = i_first ? (mine.lane | mine.nl << 3 | (int)mine.offL << 6 | (int)mine.offR << 7)
-                                    : (v.lane | nl_self << 3 | (int)offL << 6 | (int)offR << 7);
+            const int spk = i_first ? mine.pk : pk_self;
             const double ox = dppx_d<m>(sx_), oy = dppx_d<m>(sy_), oh = dppx_d<m>(sh_);
             const int opk = dppx_i<m>(spk | (int)live << 8);
             const bool o_first = !i_first && p_rank < 99;  // partner steps before me (ranks are distinct)
-            const Rel r = relate(v.x, v.y, v.lane, nl_self, ((opk >> 8) & 1) != 0, ox, oy, oh, opk & 7, (opk >> 3) & 7,
-                                 ((opk >> 6) & 1) != 0, ((opk >> 7) & 1) != 0);
+            const Rel r = relate(v.x, v.y, pk_self, ((opk >> 8) & 1) != 0, ox, oy, oh, opk);
             s_cold[kColdB + m - 1][tid] = r.key;
             // running "first in sorted order" per class: smaller key, ties by creation index (selects, no branches)
             // (the slot's flags ride in the index word -- bit 4: that partner steps before me, bit 5: its corner
@@ -1075,7 +1069,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           irregular = irregular || (shield_on && nb.has_oar && oar_stepped);
           // ---- MASS: fixed point over the decided accelerations (HSS: one evaluation) ----------
           double acc_cur = shield_on ? 0.0 : v.act_acc;  // vehicles without a shield keep their command
-          const ShieldStatic ss = shield_static<MASS>(c, v, cpsi, offL, offR, nb);
+          const ShieldStatic ss = shield_static<MASS>(c, v, cpsi, pk_self, nb);
           for (int round = 0; round <= st.N; round++) {
             if (MASS) {
               const double gu_cur = slot_gu<true>(h1vx_mine, acc_cur, mine.gvx, dt);  // my post-step record under my current decision
@@ -1114,8 +1108,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         // working copy of what the others see of me; committed stage by stage
         double wx = v.x, wy = v.y, wh = v.h, wg = hdv ? 1.0 : v.gvx, wacc = hdv ? kCbfAccLo : s_cold[C_SACC][tid], wvx = v.v * cpsi;
         double whx = s_cold[C_H2X][tid], whvx = s_cold[C_H2VX][tid];
-        int wlane = v.lane, wnl = nl_self;
-        bool woffL = offL, woffR = offR;
+        int wpk = pk_self;
         if (MIXED && hdv && live) {
           // HDVs take no part in the shield: publish their stepped view when the sweep passes them
           // (done below by rank), here only note that their record [-2] after stepping is the old [-1]
@@ -1129,7 +1122,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
             // an HDV at its turn just steps (no shield): later egos see its post-step pose, and its
             // state_hist[-2] is then the record it held as [-1] before
             const Cand ca = chosen(false);
-            wx = ca.x; wy = ca.y; wh = ca.h; wlane = ca.lane; wnl = ca.nl; woffL = ca.offL; woffR = ca.offR;
+            wx = ca.x; wy = ca.y; wh = ca.h; wpk = ca.pk;
             whx = s_cold[C_H1X][tid]; whvx = s_cold[C_H1VX][tid]; w_stepped = true; twin_shift = 0;
             wgu = slot_gu<MASS>(whvx, MASS ? wacc : kCbfAccLo, wg, dt);
           }
@@ -1138,9 +1131,9 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           const int ai = has ? (__ffs((int)sel) - 1) : 0;
           const int src = gb + ai;
           const double ex = shfl_d(v.x, src), ey = shfl_d(v.y, src);
-          const int epk = shfl_i(v.lane | (nl_self << 4), src);
+          const int epk = shfl_i(pk_self, src);
           const double e_vx = shfl_d(v.v * cpsi, src);  // vehicle.velocity[0] of the ego
-          const Rel rl = relate(ex, ey, epk & 15, epk >> 4, live && has && a != ai, wx, wy, wh, wlane, wnl, woffL, woffR, hdv);
+          const Rel rl = relate(ex, ey, epk, live && has && a != ai, wx, wy, wh, wpk, hdv);
           int pos = 0;
           for_partners<G>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
@@ -1189,7 +1182,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           if (has_tw) { nb.constrain_adj = MASS; hss_collab = !MASS; }  // cbf.constrain_adj = True (:181)
           // (absent slots contribute g*u = 0, an obstacle +0: handled in shield_dyn<.., PRE> / obstacle_override)
           obstacle_override<MASS>(nb, v.x, v.y);
-          ShieldOut s1 = shield_eval<MASS, true>(c, v, cpsi, offL, offR, nb);
+          ShieldOut s1 = shield_eval<MASS, true>(c, v, cpsi, pk_self, nb);
           if (hss_collab) s1.flags |= MM_FLAG_IS_COLLABORATING;  // vehicle.is_collaborating = cbf.constrain_adj
           if (has && a == ai && shield_on) {
             new_acc = s1.acc; veto = s1.veto; new_flags = s1.flags; qt = s1.qt;
@@ -1200,7 +1193,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
             nv = nv > 0 ? nv : 0;
             // publish my post-step view (Vehicle.step committed) for the later stages
             wx = cc.x; wy = cc.y; wh = cc.h; wg = cc.gvx; wacc = new_acc; wvx = nv * cc.cpsi;
-            whx = s_cold[C_H1X][tid]; whvx = s_cold[C_H1VX][tid]; wlane = cc.lane; wnl = cc.nl; woffL = cc.offL; woffR = cc.offR;
+            whx = s_cold[C_H1X][tid]; whvx = s_cold[C_H1VX][tid]; wpk = cc.pk;
             wgu = slot_gu<MASS>(whvx, MASS ? wacc : kCbfAccLo, wg, dt);
           }
         }
@@ -1238,7 +1231,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         if (v.hist_len < 2) v.hist_len++;
       }
       if (SHIELDED || MIXED) cpsi = cc.cpsi;
-      if (SHIELDED) { offL = cc.offL; offR = cc.offR; nl_self = cc.nl; }
+      if (SHIELDED) pk_self = cc.pk;
     }
 
     STAMP(7);  // commit
@@ -1533,12 +1526,8 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
   if (valid) { v.act_steer = act_steer[i]; v.act_acc = act_acc[i]; }
   const bool on = ctrl && SHIELD != MM_SHIELD_NONE && v.hist_len >= 2;  // gate safe_controller.py:229-239
   const double cpsi = v.present ? mmm_cos(v.h) : 1.0;
-  bool offL = false, offR = false;
-  int nl_self = 0;
-  if (v.present) {
-    corner_flags(v.x, v.y, v.h, v.lane, offL, offR);
-    nl_self = next_lane(v.lane, v.x, v.y);
-  }
+  int pk_self = v.lane;
+  if (v.present) pk_self = pose_code(v.lane, next_lane(v.lane, v.x, v.y), corner_flags(v.x, v.y, v.h, v.lane));
   // every other vehicle is seen in its CURRENT state: records [-2], last safe_action, g.vx as stored
   double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
   int j_ol = -1, j_oa = -1, j_oar = -1;
@@ -1552,13 +1541,12 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
     constexpr int m = decltype(mc)::value;
     const int p = a ^ m;
     const double ox = dppx_d<m>(v.x), oy = dppx_d<m>(v.y), oh = dppx_d<m>(v.h);
-    const int opk = dppx_i<m>(v.lane | nl_self << 3 | (int)offL << 6 | (int)offR << 7 | (int)v.present << 8 | (int)hdv << 9);
+    const int opk = dppx_i<m>(pk_self | (int)v.present << 8 | (int)hdv << 9);
     const double ohx = dppx_d<m>(v.h2x), ohvx = dppx_d<m>(v.h2vx);
     const double og = dppx_d<m>(hdv ? 1.0 : v.gvx), oacc = dppx_d<m>(hdv ? kCbfAccLo : v.safe_acc);
     const double ovx = dppx_d<m>(v.v * cpsi);
     const bool o_hdv = ((opk >> 9) & 1) != 0;
-    const Rel r = relate(v.x, v.y, v.lane, nl_self, ((opk >> 8) & 1) != 0, ox, oy, oh, opk & 7, (opk >> 3) & 7,
-                         ((opk >> 6) & 1) != 0, ((opk >> 7) & 1) != 0, o_hdv);
+    const Rel r = relate(v.x, v.y, pk_self, ((opk >> 8) & 1) != 0, ox, oy, oh, opk, o_hdv);
     keys[m] = r.key;
     if (r.cls == 1 && (r.key < k_ol || (r.key == k_ol && p < j_ol))) { k_ol = r.key; j_ol = p; nb.ol_x = ohx; nb.ol_vx = ohvx; nb.ol_g = og; nb.ol_acc = oacc; }
     if (r.cls == 2 && (r.key < k_oa || (r.key == k_oa && p < j_oa))) { k_oa = r.key; j_oa = p; nb.oa_x = ohx; nb.oa_vx = ohvx; nb.oa_g = og; nb.oa_acc = oacc; nb.constrain_adj = r.cflag; }
@@ -1608,7 +1596,7 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
   if (!nb.has_oa) { nb.oa_acc = 0; nb.oa_g = 0; }
   if (!MASS) { nb.ol_acc = kCbfAccLo; nb.oa_acc = kCbfAccLo; }
   obstacle_override<MASS>(nb, v.x, v.y);
-  ShieldOut so = shield_eval<MASS>(c, v, cpsi, offL, offR, nb);
+  ShieldOut so = shield_eval<MASS>(c, v, cpsi, pk_self, nb);
   if (hss_collab) so.flags |= MM_FLAG_IS_COLLABORATING;
   if (valid) {
     double ss = v.act_steer, sa = v.act_acc;
