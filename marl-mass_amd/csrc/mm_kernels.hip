@@ -1222,7 +1222,9 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
       if (LC) {
         if (!hdv) {
           // a veto re-steers to the current lane; identical to the nominal command unless B was needed
-          s_cold[C_SSTEER][tid] = (SHIELDED && shield_on && veto && haveB) ? s_cold[C_B + 5][tid] : v.act_steer;
+          // (shielded kernels: the nominal command was parked with candidate A -- its register is free since then)
+          const double steer_nom = SHIELDED ? s_cold[C_A + 5][tid] : v.act_steer;
+          s_cold[C_SSTEER][tid] = (SHIELDED && shield_on && veto && haveB) ? s_cold[C_B + 5][tid] : steer_nom;
           s_cold[C_SACC][tid] = acc; v.gvx = cc.gvx;
           if (sv) v.sang += s_cold[C_SSTEER][tid] * dt;  // steering_angle += safe steering velocity * dt (:139)
         }
@@ -1276,8 +1278,9 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     if (out.trace && live) {
       double *t = out.trace + (long long)k * MM_T_COUNT * A + i;
       t[MM_T_X * A] = v.x; t[MM_T_Y * A] = v.y; t[MM_T_HEADING * A] = v.h; t[MM_T_SPEED * A] = v.v;
-      t[MM_T_ACT_STEER * A] = v.act_steer; t[MM_T_ACT_ACC * A] = v.act_acc;
-      t[MM_T_SAFE_STEER * A] = (LC && !hdv) ? s_cold[C_SSTEER][tid] : v.act_steer;
+      const double steer_tr = SHIELDED ? s_cold[C_A + 5][tid] : v.act_steer;
+      t[MM_T_ACT_STEER * A] = steer_tr; t[MM_T_ACT_ACC * A] = v.act_acc;
+      t[MM_T_SAFE_STEER * A] = (LC && !hdv) ? s_cold[C_SSTEER][tid] : steer_tr;
       t[MM_T_SAFE_ACC * A] = (LC && !hdv) ? s_cold[C_SACC][tid] : v.act_acc;
       t[MM_T_LANE * A] = v.lane; t[MM_T_TARGET_LANE * A] = v.tlane; t[MM_T_CRASHED * A] = v.crashed;
       t[MM_T_FLAGS * A] = v.flags;
