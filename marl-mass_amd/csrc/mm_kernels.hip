@@ -812,7 +812,11 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   // (C_GU0 / C_GU1: parallel form only -- the g*u product of my pre- / post-step record for the askers' gather)
   enum { C_B = 0, C_H1X = 7, C_H1VX, C_H2X, C_H2VX, C_SSTEER, C_SACC, C_TSPEED, C_A = 14, C_GU0 = 21, C_GU1 = 22, kColdB = 23 };
   // unshielded kernels use only slots 7..13 (+ the obs staging: 15 slots); the sort keys are a parallel-form temporary
-  constexpr int kColdN = !SHIELDED ? 15 : (kSerialOnly ? 21 : kColdB + G - 1);
+  // kRoomy: parallel-form kernels with 8-lane groups or smaller have LDS to spare for two more per-lane values
+  // (cos(heading) and g.vx of the current pose: read two or three times per pass)
+  constexpr bool kRoomy = SHIELDED && !kSerialOnly && G <= 8;
+  constexpr int C_CPSI = kColdB + G - 1, C_GVX = C_CPSI + 1;
+  constexpr int kColdN = !SHIELDED ? 15 : (kSerialOnly ? 21 : kColdB + G - 1 + (kRoomy ? 2 : 0));
   static_assert(kColdN * MM_STEP_BLOCK * 8 >= (MM_STEP_BLOCK / 64) * 64 * 30 * 4, "the obs staging must fit in the cold slots");
   __shared__ double s_cold[kColdN][MM_STEP_BLOCK];
   const int tid = threadIdx.x;
@@ -821,6 +825,9 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     s_cold[C_SSTEER][tid] = v.safe_steer; s_cold[C_SACC][tid] = v.safe_acc;
   }
   s_cold[C_TSPEED][tid] = v.tspeed;
+  if (kRoomy) { s_cold[C_CPSI][tid] = cpsi; s_cold[C_GVX][tid] = v.gvx; }
+  auto CPSI = [&]() -> double { return kRoomy ? s_cold[C_CPSI][tid] : cpsi; };
+  auto GVX = [&]() -> double { return kRoomy ? s_cold[C_GVX][tid] : v.gvx; };
   bool env_active = n_ctrl > 0;
   STAMP(0);  // load + setup
   for (int k = 0; k < c.nsub; k++) {
@@ -997,7 +1004,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         for (int pass = 0; pass <= st.N; pass++) {
           const Cand mine = chosen(use_B);
           const double h1vx_mine = s_cold[C_H1VX][tid];
-          s_cold[C_GU0][tid] = slot_gu<MASS>(s_cold[C_H2VX][tid], MASS ? s_cold[C_SACC][tid] : kCbfAccLo, v.gvx, dt);
+          s_cold[C_GU0][tid] = slot_gu<MASS>(s_cold[C_H2VX][tid], MASS ? s_cold[C_SACC][tid] : kCbfAccLo, GVX(), dt);
           s_cold[C_GU1][tid] = slot_gu<MASS>(h1vx_mine, kCbfAccLo, mine.gvx, dt);  // (MASS: the rounds exchange the live value)
           double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
           int j_ol = -1, j_oa = -1, j_oar = -1;
@@ -1056,7 +1063,8 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           nb.ol_x = s_cold[ol_first ? C_H1X : C_H2X][t_ol]; nb.ol_gu = s_cold[ol_first ? C_GU1 : C_GU0][t_ol];
           nb.oa_x = s_cold[oa_first ? C_H1X : C_H2X][t_oa]; nb.oa_gu = s_cold[oa_first ? C_GU1 : C_GU0][t_oa];
           const int src_ol = gb + (j_ol < 0 ? 0 : j_ol), src_oa = gb + (j_oa < 0 ? 0 : j_oa), src_oar = gb + (j_oar < 0 ? 0 : j_oar);
-          nb.oar_x = shfl_d(v.x, src_oar); nb.oar_vx = shfl_d(v.v * cpsi, src_oar);  // rear adjacent: its current to_dict()
+          const double cpsi_now = CPSI();
+          nb.oar_x = shfl_d(v.x, src_oar); nb.oar_vx = shfl_d(v.v * cpsi_now, src_oar);  // rear adjacent: its current to_dict()
           // MASS: a neighbour that has stepped shows the acceleration it DECIDED this sub-step -> rounds below
           bool ol_dyn = MASS && nb.has_ol && ol_first, oa_dyn = MASS && nb.has_oa && oa_first;
           {
@@ -1069,7 +1077,8 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           irregular = irregular || (shield_on && nb.has_oar && oar_stepped);
           // ---- MASS: fixed point over the decided accelerations (HSS: one evaluation) ----------
           double acc_cur = shield_on ? 0.0 : v.act_acc;  // vehicles without a shield keep their command
-          const ShieldStatic ss = shield_static<MASS>(c, v, cpsi, pk_self, nb);
+          if (kRoomy) v.gvx = GVX();
+          const ShieldStatic ss = shield_static<MASS>(c, v, cpsi_now, pk_self, nb);
           for (int round = 0; round <= st.N; round++) {
             if (MASS) {
               const double gu_cur = slot_gu<true>(h1vx_mine, acc_cur, mine.gvx, dt);  // my post-step record under my current decision
@@ -1106,6 +1115,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         make_B();
         use_B = false; veto = false; new_acc = v.act_acc; new_flags = v.flags;
         // working copy of what the others see of me; committed stage by stage
+        if (kRoomy) { v.gvx = GVX(); cpsi = CPSI(); }
         double wx = v.x, wy = v.y, wh = v.h, wg = hdv ? 1.0 : v.gvx, wacc = hdv ? kCbfAccLo : s_cold[C_SACC][tid], wvx = v.v * cpsi;
         double whx = s_cold[C_H2X][tid], whvx = s_cold[C_H2VX][tid];
         int wpk = pk_self;
@@ -1226,13 +1236,15 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           const double steer_nom = SHIELDED ? s_cold[C_A + 5][tid] : v.act_steer;
           s_cold[C_SSTEER][tid] = (SHIELDED && shield_on && veto && haveB) ? s_cold[C_B + 5][tid] : steer_nom;
           s_cold[C_SACC][tid] = acc; v.gvx = cc.gvx;
+          if (kRoomy) s_cold[C_GVX][tid] = cc.gvx;
           if (sv) v.sang += s_cold[C_SSTEER][tid] * dt;  // steering_angle += safe steering velocity * dt (:139)
         }
         s_cold[C_H2X][tid] = s_cold[C_H1X][tid]; s_cold[C_H2VX][tid] = s_cold[C_H1VX][tid];  // log_step :187-201 (IDMVehicleHist: behavior.py:505-521)
         s_cold[C_H1X][tid] = v.x; s_cold[C_H1VX][tid] = v.v * cc.cpsi;
         if (v.hist_len < 2) v.hist_len++;
       }
-      if (SHIELDED || MIXED) cpsi = cc.cpsi;
+      if (kRoomy) s_cold[C_CPSI][tid] = cc.cpsi;
+      else if (SHIELDED || MIXED) cpsi = cc.cpsi;
       if (SHIELDED) pk_self = cc.pk;
     }
 
