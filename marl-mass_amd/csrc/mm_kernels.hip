@@ -286,6 +286,11 @@ MM_DEV int adj_lane(int l1, int nl1, int l2) {
   const int f = adj_pair(l1, l2);
   return f != 0 ? f : adj_pair(nl1, l2);
 }
+// The same relation as 2-bit codes (0: none, 1: +1, 3: -1) in packed 6-entry tables, for the classification
+// loops (one table build per ego instead of four compare chains per pair):
+//   adj_row(l1) >> 2*l2 & 3 = code of adj_pair(l1, l2);   adj_col(l2) >> 2*l1 & 3 = code of adj_pair(l1, l2)
+MM_DEV unsigned adj_row(int l1) { return l1 == MM_LANE_BC0 ? (3u << (2 * MM_LANE_BC1)) : (l1 == MM_LANE_BC1 ? (1u << (2 * MM_LANE_BC0)) : 0u); }
+MM_DEV unsigned adj_col(int l2) { return l2 == MM_LANE_BC1 ? (3u << (2 * MM_LANE_BC0)) : (l2 == MM_LANE_BC0 ? (1u << (2 * MM_LANE_BC1)) : 0u); }
 
 struct QpTrace {
   double rows, a, h0, h1, h2, h3, d, margin;
@@ -709,17 +714,24 @@ MM_DEV Rel relate(double ex, double ey, int epk, bool other, double ox, double o
   const double esx = lane_sx(elane);
   const double ld = (ox - esx) - (ex - esx);  // kinematics.py:161-173
   r.key = close ? fabs(ld) : INFINITY;
-  const int v_a = adj_lane(elane, enl, olane), a_v = adj_lane(olane, onl, elane);
+  // v_a = adj_lane(elane, enl, olane): row of elane, entries it leaves empty filled from the row of enl
+  const unsigned rowE = adj_row(elane), rowN = adj_row(enl);
+  const unsigned nzE = (rowE | rowE >> 1) & 0x555u;
+  const unsigned rowEN = rowE | (rowN & ~(nzE * 3u));
+  const unsigned colE = adj_col(elane);  // a_v = adj_lane(olane, onl, elane)
+  const unsigned va_c = (rowEN >> (2 * olane)) & 3u;
+  const unsigned g1 = (colE >> (2 * olane)) & 3u, g2 = (colE >> (2 * onl)) & 3u;
+  const unsigned av_c = g1 != 0 ? g1 : g2;
   const bool head = (dy < 0) ? (oh > 0.037) : (oh < -0.037);
   const bool appr = (!(ld < 0)) & (fabs(dy) <= 3.5) & head;  // :46-57
-  const bool adj = (!appr) & ((v_a | a_v) != 0);
+  const bool adj = (!appr) & ((va_c | av_c) != 0);
   const bool same = (elane == olane) | (olane == enl);  // is_same_lane :15-20
   // :162-184 HDV on the merging lane next to an ego on ab0: "digital twin" slot (class 4)
   const bool twin = o_hdv & (!adj) & (elane == MM_LANE_AB0) & (olane == MM_LANE_KB0) & (ld >= 0);
   const bool lead = (!adj) & (!twin) & (same | appr) & (ld > 0);
   const int cls = adj ? ((ld < 0) ? 3 : 2) : (twin ? 4 : (lead ? 1 : 0));
   r.cls = close ? cls : 0;
-  r.cflag = ((opk >> (((v_a == -1) | (a_v == 1)) ? 6 : 7)) & 1) != 0;  // :146-152 which front corner of `o`
+  r.cflag = ((opk >> (((va_c == 3u) | (av_c == 1u)) ? 6 : 7)) & 1) != 0;  // (v_a == -1 or a_v == 1; :146-152 which front corner of `o`)
   return r;
 }
 
