@@ -1013,6 +1013,9 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         // not drag 10 neighbour fields and their select chains through 7 (15) partners.
         static_assert(!MIXED || kSerialOnly, "the parallel form is CAV-only (the twin branch needs the literal sweep)");
         bool irregular = false;
+        // can a vehicle have more than 5 others around it at all?  (compile-time only: making the 8-lane kernels
+        // test st.N > 6 as well cost them 3 % through 20 B/lane more scratch)
+        constexpr bool count5 = G > 4;
         for (int pass = 0; pass <= st.N; pass++) {
           const Cand mine = chosen(use_B);
           const double h1vx_mine = s_cold[C_H1VX][tid];
@@ -1032,7 +1035,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
             const int opk = dppx_i<m>(spk | (int)live << 8);
             const bool o_first = !i_first && p_rank < 99;  // partner steps before me (ranks are distinct)
             const Rel r = relate(v.x, v.y, pk_self, ((opk >> 8) & 1) != 0, ox, oy, oh, opk);
-            s_cold[kColdB + m - 1][tid] = r.key;
+            if (count5) s_cold[kColdB + m - 1][tid] = r.key;
             // running "first in sorted order" per class: smaller key, ties by creation index (selects, no branches)
             // (the slot's flags ride in the index word -- bit 4: that partner steps before me, bit 5: its corner
             // flag -- instead of living as lane masks through the loop: 84 fewer SGPR spills)
@@ -1051,7 +1054,9 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           Neigh nb;
           memset(&nb, 0, sizeof nb);
           // count = 5 of close_vehicles_to: a slot exists only if its vehicle is among the 5 nearest
-          {
+          // (with at most 6 vehicles per env every other vehicle is: the position count is skipped)
+          nb.has_ol = j_ol >= 0; nb.has_oa = j_oa >= 0; nb.has_oar = j_oar >= 0;
+          if (count5) {
             int pos_ol = 0, pos_oa = 0, pos_oar = 0;
 #pragma unroll
             for (int m = 1; m < G; m++) {
@@ -1061,9 +1066,9 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
               pos_oa += (km < k_oa || (km == k_oa && p < j_oa)) ? 1 : 0;
               pos_oar += (km < k_oar || (km == k_oar && p < j_oar)) ? 1 : 0;
             }
-            nb.has_ol = j_ol >= 0 && pos_ol < 5;
-            nb.has_oa = j_oa >= 0 && pos_oa < 5;
-            nb.has_oar = j_oar >= 0 && pos_oar < 5;
+            nb.has_ol = nb.has_ol && pos_ol < 5;
+            nb.has_oa = nb.has_oa && pos_oa < 5;
+            nb.has_oar = nb.has_oar && pos_oar < 5;
           }
           nb.constrain_adj = MASS && nb.has_oa && cadj;
           // gather the chosen neighbours' records from their owners' columns (same wave: program order + a
