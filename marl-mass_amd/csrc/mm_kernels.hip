@@ -257,7 +257,8 @@ struct Cand {
   int lane;  // closest lane of the post-state
   int pk;    // its pose code (SHIELDED only)
 };
-template <int KIND, bool SHIELDED>
+// CORNERS: the front-corner bits are read by MASS only (constrain_adj, can_abort_lc): HSS kernels skip them
+template <int KIND, bool SHIELDED, bool CORNERS = SHIELDED>
 MM_DEV Cand predict(const Veh &v, double steer, double dt, bool sv = false) {
   Cand c;
   // "steer_vel" (safe_controller.py:124-150): the slip angle comes from the steering-angle STATE and the
@@ -272,7 +273,7 @@ MM_DEV Cand predict(const Veh &v, double steer, double dt, bool sv = false) {
   c.lane = closest_lane(c.x, c.y, c.h);  // on_state_update kinematics.py:154-159
   c.cpsi = (KIND == MM_ENV_V1) ? mmm_cos(c.h) : 0.0;
   c.pk = c.lane;
-  if (SHIELDED) c.pk = pose_code(c.lane, next_lane(c.lane, c.x, c.y), corner_flags(c.x, c.y, c.h, c.lane));
+  if (SHIELDED) c.pk = pose_code(c.lane, next_lane(c.lane, c.x, c.y), CORNERS ? corner_flags(c.x, c.y, c.h, c.lane) : 0);
   return c;
 }
 
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   // derived per-vehicle registers the shield keeps current across sub-steps
   double cpsi = ((SHIELDED || MIXED) && v.present) ? mmm_cos(v.h) : 1.0;
   int pk_self = v.lane;  // pose code of my current (pre-step) pose
-  if (SHIELDED && v.present) pk_self = pose_code(v.lane, next_lane(v.lane, v.x, v.y), corner_flags(v.x, v.y, v.h, v.lane));
+  if (SHIELDED && v.present) pk_self = pose_code(v.lane, next_lane(v.lane, v.x, v.y), MASS ? corner_flags(v.x, v.y, v.h, v.lane) : 0);
 
   // Register relief: lane-private values that are written once and read rarely live in LDS ("cold"
   // slots, one column per thread) instead of being spilled to scratch by the compiler (measured: each
@@ -954,7 +955,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     Cand cA;
     memset(&cA, 0, sizeof cA);
     const bool shield_on = SHIELDED && live && !hdv && v.hist_len >= 2;  // gate safe_controller.py:232-239
-    if (live) cA = predict<KIND, SHIELDED>(v, v.act_steer, dt, sv && !hdv);
+    if (live) cA = predict<KIND, SHIELDED, MASS>(v, v.act_steer, dt, sv && !hdv);
     auto park = [&](int base, const Cand &cc, double steer) {  // a candidate's LDS image
       s_cold[base + 0][tid] = cc.x; s_cold[base + 1][tid] = cc.y; s_cold[base + 2][tid] = cc.h;
       s_cold[base + 3][tid] = cc.gvx; s_cold[base + 4][tid] = cc.cpsi; s_cold[base + 5][tid] = steer;
@@ -973,7 +974,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
       if (SHIELDED && needB && !haveB) {
         double steerB = steering_control(v.x, v.y, v.h, v.v, v.lane);
         if (sv) steerB = steer_vel_command(steerB, v.sang);
-        park(C_B, predict<KIND, true>(v, steerB, dt, sv), steerB);
+        park(C_B, predict<KIND, true, MASS>(v, steerB, dt, sv), steerB);
         haveB = true;
       }
     };
@@ -1559,7 +1560,7 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
   const bool on = ctrl && SHIELD != MM_SHIELD_NONE && v.hist_len >= 2;  // gate safe_controller.py:229-239
   const double cpsi = v.present ? mmm_cos(v.h) : 1.0;
   int pk_self = v.lane;
-  if (v.present) pk_self = pose_code(v.lane, next_lane(v.lane, v.x, v.y), corner_flags(v.x, v.y, v.h, v.lane));
+  if (v.present) pk_self = pose_code(v.lane, next_lane(v.lane, v.x, v.y), MASS ? corner_flags(v.x, v.y, v.h, v.lane) : 0);
   // every other vehicle is seen in its CURRENT state: records [-2], last safe_action, g.vx as stored
   double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
   int j_ol = -1, j_oa = -1, j_oar = -1;
