@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 4
+#define MM_ABI_VERSION 5
 #define MM_MAX_AGENTS 16 /* vehicles per env (reference draws 2..11, merge_env_v1.py:180-211) */
 #define MM_N_ACTIONS 5   /* DiscreteMetaAction.ACTIONS_ALL, envs/common/action.py:141-147 */
 #define MM_OBS_ROWS 5    /* KinematicObservation vehicles_count, envs/common/observation.py:132 */
@@ -142,8 +142,15 @@ typedef struct MMConfig {
   int32_t lateral_control;      /* config["lateral_control"] (merge_env_v1.py:499, safe_controller.py:30-44):
                                    MM_LATERAL_STEER (1st-order, default) | MM_LATERAL_STEER_VEL (steering velocity,
                                    KP_STEER 20, STEER_TARGET_RF 0.125); v1 CAVs only, as in the reference */
-  int32_t reserved0;
+  int32_t qp_solver;            /* how the shield's QP (cbf.py:128-135, cvxopt.solvers.qp) is solved:
+                                   MM_QP_EXACT  its exact KKT point in closed form (default, production);
+                                   MM_QP_IPM    fidelity mode: the interior-point iterate cvxopt's coneqp algorithm
+                                                stops at (Mehrotra predictor-corrector, NT scaling, abstol 1e-7 /
+                                                reltol 1e-6 / feastol 1e-7, <= 100 iterations), incl. its "unknown"
+                                                status -> is_optimal = 0 (include/mm_qp.h) */
 } MMConfig;
+#define MM_QP_EXACT 0
+#define MM_QP_IPM 1
 
 /*
  * Outputs of one step.  Any pointer may be NULL (that output is skipped).  DEV pointers.
@@ -181,7 +188,8 @@ enum {
                                      lane change allowed <=> margin >= 0.  Structurally ~0 (sign =
                                      rounding noise) when the adjacent CBF row is the active one */
   MM_T_STATUS,                    /* MM_ST_* bits of the in-step shield call (is_optimal / is_safe / is_invariant,
-                                     cbf.py:341-357); NaN if the shield did not run                         */
+                                     cbf.py:341-357; MM_ST_QP_BOUNDS if check_bounds would have raised);
+                                     NaN if the shield did not run                                          */
   MM_T_HEADWAY,                   /* vehicle.min_headway set by the shield: (x_ol - x_e - LENGTH) / vx_e
                                      (decentral_layer.py:466,700); NaN if the shield did not run             */
   MM_T_COUNT
@@ -243,11 +251,20 @@ int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStre
 /*
  * Stand-alone batched shield QP (unit parity of cbf.py:110-161 + cvxopt.solvers.qp):
  *   min 1/2 (d^2 + e^2 + 1e18 s^2)  s.t.  G u <= h,  u = (d, e, s),
+ * for the G the reference's get_G builds (cbf.py:288-304,386-403) and no other:
+ *   rows [a 0 -1], [1 0 0], [-1 0 0] and, with rows[k] == 4, a fourth [a 0 -1].
  * G: DEV double[n][4][3] row-major, h: DEV double[n][4], rows: DEV int32[n] (3 or 4).
- * u_out: DEV double[n][3]; status: DEV uint8[n] (1 = optimal).
+ * solver: MM_QP_EXACT | MM_QP_IPM (see MMConfig.qp_solver).
+ * u_out: DEV double[n][3]; status: DEV uint8[n] -- MM_QPS_OPTIMAL, MM_QPS_UNKNOWN (the IPM stopped at its
+ * iteration cap or on a singular KKT matrix: sol["status"] == "unknown", cbf.py:140) or MM_QPS_BAD_STRUCTURE
+ * (G is not of the form above: u_out is NaN and the call returns MM_ERR_INVALID_ARG);
+ * iters: DEV int32[n] IPM iteration counts or NULL.  Synchronises the stream (a unit entry, not a hot one).
  */
-int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec,
-                     const int32_t *rows, double *u_out, uint8_t *status, MMStream stream);
+#define MM_QPS_UNKNOWN 0u
+#define MM_QPS_OPTIMAL 1u
+#define MM_QPS_BAD_STRUCTURE 255u
+int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec, const int32_t *rows,
+                     int32_t solver, double *u_out, uint8_t *status, int32_t *iters, MMStream stream);
 
 /*
  * safety_layer(safety_type, action, vehicle, dt, ...) (decentral_layer.py:767-817; call site
@@ -266,8 +283,20 @@ int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec,
 #define MM_ST_IS_LC_SAFE 16u   /* vehicle.is_lc_safe: no lane-change veto */
 #define MM_ST_IS_COLLABORATING 32u
 #define MM_ST_COLLABORATE_ADJ 64u
+#define MM_ST_QP_BOUNDS 128u   /* CBFType.check_bounds (cbf.py:87-96) would have raised ValueError: u_safe[0] is
+                                  more than 1e-3 outside [v_min, v_max]; the call returns MM_ERR_QP_BOUNDS */
 int32_t mm_shield_actions(MMHandle h, const double *act_steer, const double *act_acc, double *safe_steer,
                           double *safe_acc, uint8_t *status, double *margin, MMStream stream);
+
+/*
+ * Errors a launch cannot return synchronously.  mm_step / mm_reset only enqueue work; conditions the
+ * reference raises from inside step() -- check_bounds' ValueError (cbf.py:87-96), an action outside 0..4
+ * (KeyError in DiscreteMetaAction.act, action.py:194-196) -- are latched in a device word of the handle.
+ * This call synchronises `stream`, returns MM_ERR_QP_BOUNDS / MM_ERR_INVALID_ARG (message in mm_last_error)
+ * if one was latched since the last poll, else MM_OK, and clears the latch.  mm_shield_qp and
+ * mm_shield_actions poll it themselves.
+ */
+int32_t mm_poll_errors(MMHandle h, MMStream stream);
 
 /*
  * Rollout metric accumulator (the only cross-GPU quantity): adds this step's

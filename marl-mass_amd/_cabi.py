@@ -7,7 +7,7 @@ shared object is loaded is decided by the caller, never silently.
 import ctypes as C
 import os
 
-MM_ABI_VERSION = 4
+MM_ABI_VERSION = 5
 MM_MAX_AGENTS = 16
 ENV_V0, ENV_V1 = 0, 1
 SHIELD_NONE, SHIELD_HSS, SHIELD_MASS = 0, 1, 2
@@ -29,6 +29,9 @@ FLAG_COLLABORATE_ADJ, FLAG_IS_LC_SAFE, FLAG_IS_COLLABORATING = 1, 2, 4
 HL_NONE = 255
 
 ST_RAN, ST_IS_OPTIMAL, ST_IS_SAFE, ST_IS_INVARIANT, ST_IS_LC_SAFE, ST_IS_COLLABORATING, ST_COLLABORATE_ADJ = 1, 2, 4, 8, 16, 32, 64
+ST_QP_BOUNDS = 128
+QP_EXACT, QP_IPM = 0, 1
+QPS_UNKNOWN, QPS_OPTIMAL, QPS_BAD_STRUCTURE = 0, 1, 255
 MM_OK, MM_ERR_INVALID_ARG, MM_ERR_NOT_READY, MM_ERR_DEVICE, MM_ERR_QP_BOUNDS = 0, -1, -2, -3, -4
 
 # (from, to, id) lane tuples of the reference <-> lane ids (merge_env_v1.py:231-245)
@@ -51,7 +54,7 @@ class MMConfig(C.Structure):
                 ("merging_lane_cost", C.c_double), ("reward_speed_lo", C.c_double),
                 ("reward_speed_hi", C.c_double), ("cbf_eta", C.c_double), ("cbf_tau", C.c_double),
                 ("seed", C.c_uint64), ("n_hdv", C.c_int32), ("agent_reward", C.c_int32),
-                ("lateral_control", C.c_int32), ("reserved0", C.c_int32)]
+                ("lateral_control", C.c_int32), ("qp_solver", C.c_int32)]
 
 
 class MMStepOut(C.Structure):
@@ -61,12 +64,26 @@ class MMStepOut(C.Structure):
         "trace")]
 
 
+SUPERVISED = ("priority", "dmc")
+
+
+def check_supervisor(value):
+    """"priority" (the reference's DEFAULT, merge_env_v1.py:47) and "dmc" make AbstractEnv.step rewrite the joint
+    action through safety_supervisor / safety_layer_dmc (abstract.py:460-464) -- competing baselines outside
+    this path.  Stepping them as if unsupervised would silently change behaviour and safety,
+    so step() raises: set "none" or "cbf-*" explicitly, as run_mappo.py does from the .ini.  (reset() is
+    unaffected, as in the reference: the supervisor only acts inside step.)"""
+    if value in SUPERVISED:
+        raise NotImplementedError(
+            "safety_guarantee=%r (the reference's action-replacement supervisors, abstract.py:460-464) is not part of "
+            "this path: set env.config['safety_guarantee'] to 'none' or 'cbf-*' before stepping" % (value,))
+
+
 def shield_from_safety_guarantee(value):
-    """config["safety_guarantee"] -> shield id, as safe_controller.py:229-241 + decentral_layer.py:767-817
-    dispatch it.  Unknown "cbf-*" types raise ValueError like safety_layer does."""
-    if value in (None, "none", "priority", "dmc") or "cbf-" not in value:
-        # 'priority' / 'dmc' are the competing baselines (SURVEY 2 row 9, out of scope): the
-        # vehicle-level shield is off for them exactly as in get_safe_action.
+    """config["safety_guarantee"] -> VEHICLE-level shield id, as safe_controller.py:229-241 +
+    decentral_layer.py:767-817 dispatch it ("priority" / "dmc" have none: their supervisor sits in
+    AbstractEnv.step, see check_supervisor).  Unknown "cbf-*" types raise ValueError like safety_layer does."""
+    if value in (None, "none") or value in SUPERVISED or "cbf-" not in value:
         return SHIELD_NONE
     kind = value.split("-")[1]
     if kind in ("hss", "av", "avs", "avs_cint"):
@@ -93,8 +110,16 @@ def default_env_config(env_id):
     return cfg
 
 
+def qp_solver_id(name):
+    """'exact' (closed-form KKT point, default) | 'ipm' (cvxopt's coneqp iterate, fidelity mode)."""
+    try:
+        return {"exact": QP_EXACT, "ipm": QP_IPM, QP_EXACT: QP_EXACT, QP_IPM: QP_IPM}[name]
+    except KeyError:
+        raise ValueError("qp_solver must be 'exact' or 'ipm', got %r" % (name,))
+
+
 def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0, debug_flags=0,
-                n_hdv=0):
+                n_hdv=0, qp_solver="exact"):
     """env.config dict (+ CBFType.GAMMA_B / CBFType.TAU, run_mappo.py:138-139) -> MMConfig."""
     c = MMConfig()
     c.abi_version = MM_ABI_VERSION
@@ -124,6 +149,7 @@ def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs
     c.n_hdv = int(n_hdv)
     ar = config.get("agent_reward", "default") if c.env_kind == ENV_V1 else "default"
     c.agent_reward = {"srew": 1, "mrew": 2}.get(ar, 0)  # anything else falls back to the default reward (:446)
+    c.qp_solver = qp_solver_id(qp_solver)
     return c
 
 
@@ -133,7 +159,7 @@ class CLib(object):
     SYMBOLS = ["mm_abi_version", "mm_state_layout", "mm_create", "mm_destroy", "mm_set_config",
                "mm_reset", "mm_init_from_kinematics", "mm_observe", "mm_step", "mm_shield_qp",
                "mm_set_metrics_buffer", "mm_last_error", "mm_math_eval", "mm_shield_actions", "mm_sample_actions",
-               "mm_policy_act"]
+               "mm_policy_act", "mm_poll_errors"]
 
     def __init__(self, path):
         if not os.path.exists(path):
@@ -151,7 +177,8 @@ class CLib(object):
         lib.mm_init_from_kinematics.argtypes = [vp, vp, vp]
         lib.mm_observe.argtypes = [vp, vp, vp, vp]
         lib.mm_step.argtypes = [vp, vp, C.POINTER(MMStepOut), vp]
-        lib.mm_shield_qp.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+        lib.mm_shield_qp.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]
+        lib.mm_poll_errors.argtypes = [vp, vp]
         lib.mm_set_metrics_buffer.argtypes = [vp, vp]
         lib.mm_last_error.argtypes = [vp]
         lib.mm_math_eval.argtypes = [i32, i32, vp, vp, vp, vp]

@@ -27,6 +27,9 @@ class CBFType(object):
     TAU = 0.5
     ADJ_BUFFER = 2.0134
     ACCELERATION_RANGE = (-12.5, 6)
+    # not in the reference: how `solvers.qp` (cbf.py:134) is answered -- "exact" (closed-form KKT point) or "ipm"
+    # (the iterate cvxopt's interior-point algorithm stops at, include/mm_qp.h); read at reset like GAMMA_B / TAU
+    QP_SOLVER = "exact"
 
 
 class _VehicleView(object):
@@ -147,42 +150,39 @@ class MergeEnvCompat(object):
         return int(num_CAV), int(num_HDV)
 
     def _make_vehicles(self, num_CAV, num_HDV):
-        """merge_env_v1.py:265-364; same global-RNG draws in the same order.  Returns x, y, speed of
-        all vehicles in creation order (CAVs main, CAVs ramp, HDVs main, HDVs ramp) and n_merge."""
-        if num_CAV + num_HDV > MAX_VEHICLES:
+        """Spawn draw of merge_env_v1.py:265-364 on the GLOBAL numpy RNG.  What has to match the reference is the
+        sequence of RNG calls (a MAPPO loop seeded the same way must see the same episodes and the same
+        downstream stream): per vehicle class (CAVs, then HDVs) one `choice(2)` iff the class has exactly one
+        vehicle, then `choice(free slots, k, replace=False)` for the main road and for the ramp; finally one
+        `rand(n)` for the speeds and one for the position noise, consumed in creation order (CAVs main, CAVs
+        ramp, HDVs main, HDVs ramp).  Returns x, y, speed in that order and the number of ramp CAVs."""
+        n_all = num_CAV + num_HDV
+        if n_all > MAX_VEHICLES:
             raise ValueError("at most %d vehicles (6 + 6 spawn slots)" % MAX_VEHICLES)
-        spawn_points_s = [10, 60, 110, 160, 210, 260]
-        spawn_points_m = [5, 55, 105, 155, 205, 255]
-        num_s_c = num_CAV // 2 if num_CAV != 1 else np.random.choice(2)
-        num_m_c = num_CAV - num_s_c
-        spawn_point_s_c = list(np.random.choice(spawn_points_s, num_s_c, replace=False))
-        spawn_point_m_c = list(np.random.choice(spawn_points_m, num_m_c, replace=False))
-        for a in spawn_point_s_c:
-            spawn_points_s.remove(a)
-        for b in spawn_point_m_c:
-            spawn_points_m.remove(b)
-        num_s_h = num_HDV // 2 if num_HDV != 1 else np.random.choice(2)
-        num_m_h = num_HDV - num_s_h
-        spawn_point_s_h = list(np.random.choice(spawn_points_s, num_s_h, replace=False))
-        spawn_point_m_h = list(np.random.choice(spawn_points_m, num_m_h, replace=False))
-        initial_speed = list(np.random.rand(num_CAV + num_HDV) * 2 + 25)
-        loc_noise = list(np.random.rand(num_CAV + num_HDV) * 8 - 4)
-        x, y, v = [], [], []
-        for _ in range(num_s_c):
-            x.append(spawn_point_s_c.pop(0) + loc_noise.pop(0)); y.append(0.0); v.append(initial_speed.pop(0))
-        for _ in range(num_m_c):
-            x.append(spawn_point_m_c.pop(0) + loc_noise.pop(0)); y.append(6.5 + 4); v.append(initial_speed.pop(0))
-        for _ in range(num_s_h):
-            x.append(spawn_point_s_h.pop(0) + loc_noise.pop(0)); y.append(0.0); v.append(initial_speed.pop(0))
-        for _ in range(num_m_h):
-            x.append(spawn_point_m_h.pop(0) + loc_noise.pop(0)); y.append(6.5 + 4); v.append(initial_speed.pop(0))
-        return np.array(x, dtype=np.float64), np.array(y), np.array(v, dtype=np.float64), int(num_m_c)
+        free = {"main": [10 + 50 * k for k in range(6)], "ramp": [5 + 50 * k for k in range(6)]}
+        lane_y = {"main": 0.0, "ramp": 6.5 + 4}
+        groups = []  # (road, slots) in creation order
+        n_ramp_cav = 0
+        for cls, count in (("cav", num_CAV), ("hdv", num_HDV)):
+            on_main = count // 2 if count != 1 else np.random.choice(2)
+            split = {"main": on_main, "ramp": count - on_main}
+            if cls == "cav":
+                n_ramp_cav = split["ramp"]
+            for road in ("main", "ramp"):
+                picked = [int(p) for p in np.random.choice(free[road], split[road], replace=False)]
+                free[road] = [p for p in free[road] if p not in picked]
+                groups.append((road, picked))
+        speed = np.random.rand(n_all) * 2 + 25
+        noise = np.random.rand(n_all) * 8 - 4
+        slot = np.array([p for _, picked in groups for p in picked], dtype=np.float64)
+        y = np.array([lane_y[road] for road, picked in groups for _ in picked], dtype=np.float64)
+        return slot + noise, y, speed.astype(np.float64), int(n_ramp_cav)
 
     def _backend(self):
         if self._b is None:
             self._b = self._factory(E=1, N=MAX_VEHICLES, env_id=self.env_id, config=self.config,
                                     cbf_eta=CBFType.GAMMA_B, cbf_tau=CBFType.TAU, obs_f64=True,
-                                    trace=self.store_profile)
+                                    trace=self.store_profile, qp_solver=CBFType.QP_SOLVER)
         return self._b
 
     # -- Env API ------------------------------------------------------------------------------
@@ -203,7 +203,7 @@ class MergeEnvCompat(object):
         self.n_merge = n_merge
         self.T = int(self.config["duration"] * self.config["policy_frequency"])
         b = self._backend()
-        b.configure(self.config, cbf_eta=CBFType.GAMMA_B, cbf_tau=CBFType.TAU, n_hdv=n_hdv)
+        b.configure(self.config, cbf_eta=CBFType.GAMMA_B, cbf_tau=CBFType.TAU, n_hdv=n_hdv, qp_solver=CBFType.QP_SOLVER)
         n_all = len(x)
         self._n = n = n_cav
         pad = lambda a, fill: np.concatenate([a, np.full(MAX_VEHICLES - n_all, fill)])  # noqa: E731
@@ -235,6 +235,7 @@ class MergeEnvCompat(object):
         act = torch.ones(1, MAX_VEHICLES, dtype=torch.int32)
         act[0, :n] = torch.tensor(action, dtype=torch.int32)
         obs, reward, done, out = b.step(act.to(b.device))
+        b.poll_errors()  # check_bounds' ValueError (cbf.py:87-96) / an action outside 0..4, raised like the reference does
         if self.store_profile:
             self._log_profiles(b)
         self.steps += 1
@@ -381,12 +382,12 @@ class _CBF(object):
         Gp, hp = np.zeros((1, 4, 3)), np.zeros((1, 4))
         Gp[0, :G.shape[0]], hp[0, :h.shape[0]] = G, h
         solver = self._solver or _default_solver()
-        u_bar, status = solver.shield_qp(Gp, hp, np.array([G.shape[0]], dtype=np.int32))
+        u_bar, status = solver.shield_qp(Gp, hp, np.array([G.shape[0]], dtype=np.int32), solver=CBFType.QP_SOLVER)
         u_bar = u_bar[0].cpu().numpy()
         u_safe = u_ll[:2] + u_bar[:2]
         if u_safe[0] - 0.001 > self.action_bound[0][1] or u_safe[0] + 0.001 < self.action_bound[0][0]:
             raise ValueError("Error in QP. Invalid accceleration: {0}".format(u_safe[0]))
-        self.is_optimal = bool(status[0])
+        self.is_optimal = int(status[0]) == abi.QPS_OPTIMAL  # sol["status"] != "unknown" (cbf.py:140)
         return np.array(u_safe)
 
     def get_status(self):
@@ -397,9 +398,11 @@ _SOLVER = None
 
 
 def _default_solver():
+    """Device context for stand-alone `control_barrier` calls of CBFs built without `solver=` (the reference's
+    cbf_factory has no such argument): one minimal handle, created on first use, only ever used for mm_shield_qp."""
     global _SOLVER
     if _SOLVER is None:
-        _SOLVER = VecMergeEnv(E=1, N=2)
+        _SOLVER = VecMergeEnv(E=1, N=2, config={"safety_guarantee": "none"})
     return _SOLVER
 
 

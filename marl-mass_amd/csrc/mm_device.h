@@ -13,6 +13,7 @@
 #define MM_DEV __device__ __forceinline__
 #define MMM_FN __device__ __forceinline__
 #include "../../include/mm_math.h"
+#include "../../include/mm_qp.h"  // the shield QP through cvxopt's interior-point algorithm (MM_QP_IPM)
 
 namespace mm {
 

@@ -36,7 +36,12 @@ struct DevCfg {
   double inv_dt, rs_span, rs_ispan, rs_span2, rs_ispan2;  // host-computed reciprocals for div_c (correctly rounded 1/d)
   int agent_reward;
   int steer_vel;  // lateral_control == "steer_vel" (v1 CAVs; handled by the MIXED = general instantiations)
+  int *err;       // device error latch of the handle (MM_LATCH_* bits), read by mm_poll_errors
 };
+// conditions the reference raises from inside step(); a launch can only latch them (include/mm_abi.h: mm_poll_errors)
+#define MM_LATCH_QP_BOUNDS 1  // CBFType.check_bounds, cbf.py:87-96
+#define MM_LATCH_BAD_ACTION 2 // DiscreteMetaAction.act: self.actions[action] KeyError, action.py:194-196
+#define MM_LATCH_BAD_QP 4     // mm_shield_qp: G is not of the form get_G builds
 struct DevState {
   double *F;
   uint8_t *B;
@@ -48,7 +53,9 @@ struct DevState {
 
 // Translation units.  The library is built from this one source compiled twice (Makefile):
 //   MM_TU=1  everything except the "general" step kernels (MIXED = true: HDVs and/or steer_vel),
-//   MM_TU=2  only those, with conservative SGPR spilling (DESIGN.md "toolchain note").
+//   MM_TU=2  only those, with conservative SGPR spilling (DESIGN.md "toolchain note"),
+//   MM_TU=3  only the MM_QP_IPM fidelity-mode step kernels (IPM = true: the general kernels with the QP solved by
+//            cvxopt's interior-point algorithm, include/mm_qp.h), same flags as TU 2.
 // MM_TU=0 (default) is the single-TU form used by the tuning / diagnostic builds.
 #ifndef MM_TU
 #define MM_TU 0
@@ -550,6 +557,7 @@ struct ShieldOut {
   double acc, us0;  // derived acceleration, u_safe[0]
   bool veto;        // "Avoiding lane change" (:501-506 / :739-744)
   bool lon_safe, lon_invariant;  // CBF_AV.update_status cbf.py:341-351
+  bool optimal, bounds;          // sol["status"] != "unknown" (cbf.py:140); check_bounds would raise (cbf.py:87-96)
   double hw_num, hw_den;         // vehicle.set_min_headway = hw_num / hw_den (decentral_layer.py:466,700); the
                                  // division is left to the trace writer (it is wanted only when tracing)
   int flags;
@@ -632,8 +640,10 @@ MM_DEV double slot_gu(double vx, double acc, double g, double dt) {
   return (MASS ? g * dt : 1 * dt) * u;
 }
 // PRE: nb.ol_gu / nb.oa_gu already hold those products (computed by the lanes that own the records)
-template <bool MASS, bool PRE = false>
-MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s, const Neigh &nb) {
+// IPM: solve the QP by cvxopt's interior-point algorithm (MM_QP_IPM); `run_qp` = this lane's result is wanted (the
+// literal sweep evaluates every lane at every stage and keeps the ego's only: the others must not iterate on garbage)
+template <bool MASS, bool PRE = false, bool IPM = false>
+MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s, const Neigh &nb, bool run_qp = true) {
   const double dt = c.dt, eta = c.eta;
   ShieldOut o;
   double g2u2, g4u4;
@@ -654,12 +664,25 @@ MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s
     h3 = s.base3 + (-g0u0 + g4u4);
     hc = h3 < h0 ? h3 : h0;
   }
-  // exact KKT point of min 1/2(d^2 + e^2 + 1e18 s^2) s.t. a d - s <= hc, lo <= d <= hi
   double d;
-  if (s.g0 > 0) d = fmin(0.0, hc / s.g0);
-  else if (s.g0 < 0) d = fmax(0.0, hc / s.g0);
-  else d = 0.0;
-  d = fmin(fmax(d, -s.h2), s.h1);
+  o.optimal = true; o.bounds = false;
+  if constexpr (IPM) {
+    // the iterate cvxopt.solvers.qp stops at (cbf.py:134), its status (:140) and check_bounds (:87-96)
+    d = 0.0;
+    if (run_qp) {
+      double slack;
+      int iters;
+      o.optimal = mm_qp_ipm_cbf(s.g0, h0, s.h1, s.h2, h3, s.cadj ? 4 : 3, &d, &slack, &iters) != 0;
+      o.bounds = (s.u0 + d) - 0.001 > s.v_max || (s.u0 + d) + 0.001 < s.v_min;
+    }
+  } else {
+    // exact KKT point of min 1/2(d^2 + e^2 + 1e18 s^2) s.t. a d - s <= hc, lo <= d <= hi.  (d is clipped into
+    // [v_min - u0, v_max - u0] and v_min <= v_max, so check_bounds cannot fire in this mode.)
+    if (s.g0 > 0) d = fmin(0.0, hc / s.g0);
+    else if (s.g0 < 0) d = fmax(0.0, hc / s.g0);
+    else d = 0.0;
+    d = fmin(fmax(d, -s.h2), s.h1);
+  }
   double us0 = s.u0 + d;
   {  // update_status (cbf.py:341-351) on u_status = [u_safe (QP), u_ll[2:]]
     const double hls_lon = s.px_lon + s.q_lon;
@@ -691,10 +714,10 @@ MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s
   o.qt.margin = fmin(fmin(s.hls_lona, inv_lona), fmin(s.hls_lonr, inv_lonr));
   return o;
 }
-template <bool MASS, bool PRE = false>
-MM_DEV ShieldOut shield_eval(const DevCfg &c, const Veh &v, double cpsi, int pk_self, const Neigh &nb) {
+template <bool MASS, bool PRE = false, bool IPM = false>
+MM_DEV ShieldOut shield_eval(const DevCfg &c, const Veh &v, double cpsi, int pk_self, const Neigh &nb, bool run_qp = true) {
   const ShieldStatic s = shield_static<MASS>(c, v, cpsi, pk_self, nb);
-  return shield_dyn<MASS, PRE>(c, v, s, nb);
+  return shield_dyn<MASS, PRE, IPM>(c, v, s, nb, run_qp);
 }
 
 // Relation of vehicle `o` (as the ego currently sees it) to the ego: the branch conditions of the
@@ -739,8 +762,8 @@ MM_DEV Rel relate(double ex, double ey, int epk, bool other, double ox, double o
 // trace of the in-step shield call's status dict and min_headway (written where they are produced so that
 // they need not stay in registers)
 MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
-  t[MM_T_STATUS * A] = (double)(MM_ST_RAN | MM_ST_IS_OPTIMAL | (o.lon_safe ? MM_ST_IS_SAFE : 0u) |
-                                (o.lon_invariant ? MM_ST_IS_INVARIANT : 0u));
+  t[MM_T_STATUS * A] = (double)(MM_ST_RAN | (o.optimal ? MM_ST_IS_OPTIMAL : 0u) | (o.lon_safe ? MM_ST_IS_SAFE : 0u) |
+                                (o.lon_invariant ? MM_ST_IS_INVARIANT : 0u) | (o.bounds ? MM_ST_QP_BOUNDS : 0u));
   t[MM_T_HEADWAY * A] = o.hw_num / o.hw_den;
 }
 
@@ -760,7 +783,9 @@ template <int G, int SHIELD, bool MIXED>
 #define MM_GENERAL_NONE_WAVES 3  // mixed-traffic unshielded: 0.49 (2 waves) / 0.445 (3) / 0.51 ms (4)
 #endif
 constexpr int step_min_waves() { return SHIELD == MM_SHIELD_NONE ? (MIXED ? MM_GENERAL_NONE_WAVES : MM_NONE_WAVES) : MM_MIN_WAVES; }
-template <int G, int KIND, int SHIELD, bool MIXED>
+// IPM: the MM_QP_IPM fidelity mode (the shield's QP by cvxopt's interior-point algorithm, include/mm_qp.h); carried by
+// general (MIXED) instantiations only, which run the literal sweep -- one QP per vehicle per sub-step, as the reference
+template <int G, int KIND, int SHIELD, bool MIXED, bool IPM = false>
 #ifndef MM_STEP_BLOCK
 #define MM_STEP_BLOCK 256
 #endif
@@ -769,6 +794,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   constexpr bool LC = (KIND == MM_ENV_V1);
   constexpr bool SHIELDED = LC && (SHIELD != MM_SHIELD_NONE);
   constexpr bool MASS = (SHIELD == MM_SHIELD_MASS);
+  static_assert(!IPM || (MIXED && SHIELDED), "the IPM mode lives in the shielded general kernels");
   // Form of the shield sweep.  MASS and the general kernels (HDVs / steer_vel) run the literal front-to-back
   // sweep ONLY: compiled on its own it needs no VGPR spills (scratch 16 B/lane vs 248 B with both forms) and
   // at 65536 x 8 MASS it ties the parallel fixed-point form (0.46 vs 0.45 ms) -- the coupling through the
@@ -807,7 +833,11 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   if (!MIXED && v.kind == 2) v.kind = 1;  // CAV-only kernels: the host guarantees there are no HDVs
   const bool hdv = MIXED && v.kind == 2;
   const bool ctrl = v.present && !hdv;  // controlled vehicle (MDPVehicle / MDPLCVehicle)
-  const int action = (valid && ctrl) ? actions[i] : 1;
+  int action = (valid && ctrl) ? actions[i] : 1;
+  if ((unsigned)action > 4u) {  // self.actions[action]: KeyError in the reference (action.py:194-196) -> latched, acts as IDLE
+    atomicOr(c.err, MM_LATCH_BAD_ACTION);
+    action = 1;
+  }
   const unsigned present_bits = group_ballot<G>(v.present, gb);
   const unsigned ctrl_bits = group_ballot<G>(ctrl, gb);
   const int n_veh = __popc(present_bits), n_ctrl = __popc(ctrl_bits);
@@ -1210,9 +1240,11 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           if (has_tw) { nb.constrain_adj = MASS; hss_collab = !MASS; }  // cbf.constrain_adj = True (:181)
           // (absent slots contribute g*u = 0, an obstacle +0: handled in shield_dyn<.., PRE> / obstacle_override)
           obstacle_override<MASS>(nb, v.x, v.y);
-          ShieldOut s1 = shield_eval<MASS, true>(c, v, cpsi, pk_self, nb);
+          const bool mine = has && a == ai && shield_on;  // this stage's ego
+          ShieldOut s1 = shield_eval<MASS, true, IPM>(c, v, cpsi, pk_self, nb, mine);
           if (hss_collab) s1.flags |= MM_FLAG_IS_COLLABORATING;  // vehicle.is_collaborating = cbf.constrain_adj
-          if (has && a == ai && shield_on) {
+          if (IPM && mine && s1.bounds) atomicOr(c.err, MM_LATCH_QP_BOUNDS);
+          if (mine) {
             new_acc = s1.acc; veto = s1.veto; new_flags = s1.flags; qt = s1.qt;
             if (out.trace) trace_status(out.trace + (long long)k * MM_T_COUNT * A + i, A, s1);
             use_B = veto && needB;
@@ -1541,7 +1573,7 @@ __global__ __launch_bounds__(256) void reset_kernel(DevCfg c, DevState st, int m
 // ------------------------------------------------------------------------------------------------
 // stand-alone safety_layer(...) for every controlled vehicle on the current state (mm_shield_actions)
 // ------------------------------------------------------------------------------------------------
-template <int G, int SHIELD>
+template <int G, int SHIELD, bool IPM = false>
 __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, const double *__restrict__ act_steer,
                                                      const double *__restrict__ act_acc, double *__restrict__ safe_steer,
                                                      double *__restrict__ safe_acc, uint8_t *__restrict__ status,
@@ -1629,8 +1661,9 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
   if (!nb.has_oa) { nb.oa_acc = 0; nb.oa_g = 0; }
   if (!MASS) { nb.ol_acc = kCbfAccLo; nb.oa_acc = kCbfAccLo; }
   obstacle_override<MASS>(nb, v.x, v.y);
-  ShieldOut so = shield_eval<MASS>(c, v, cpsi, pk_self, nb);
+  ShieldOut so = shield_eval<MASS, false, IPM>(c, v, cpsi, pk_self, nb, valid && on);
   if (hss_collab) so.flags |= MM_FLAG_IS_COLLABORATING;
+  if (IPM && valid && on && so.bounds) atomicOr(c.err, MM_LATCH_QP_BOUNDS);
   if (valid) {
     double ss = v.act_steer, sa = v.act_acc;
     unsigned stt = 0;
@@ -1640,8 +1673,8 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
         ss = steering_control(v.x, v.y, v.h, v.v, v.lane);
         if (c.steer_vel) ss = steer_vel_command(ss, v.sang);
       }
-      stt = MM_ST_RAN | MM_ST_IS_OPTIMAL | (so.lon_safe ? MM_ST_IS_SAFE : 0u) | (so.lon_invariant ? MM_ST_IS_INVARIANT : 0u) |
-            ((so.flags & MM_FLAG_IS_LC_SAFE) ? MM_ST_IS_LC_SAFE : 0u) |
+      stt = MM_ST_RAN | (so.optimal ? MM_ST_IS_OPTIMAL : 0u) | (so.lon_safe ? MM_ST_IS_SAFE : 0u) | (so.lon_invariant ? MM_ST_IS_INVARIANT : 0u) |
+            (so.bounds ? MM_ST_QP_BOUNDS : 0u) | ((so.flags & MM_FLAG_IS_LC_SAFE) ? MM_ST_IS_LC_SAFE : 0u) |
             ((so.flags & MM_FLAG_IS_COLLABORATING) ? MM_ST_IS_COLLABORATING : 0u) |
             ((so.flags & MM_FLAG_COLLABORATE_ADJ) ? MM_ST_COLLABORATE_ADJ : 0u);
     }
@@ -1651,15 +1684,39 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
   }
 }
 
-// stand-alone batched shield QP (cbf.py:110-161): exact KKT point, one thread per QP
-#if MM_TU != 2
+// stand-alone batched shield QP (cbf.py:110-161), one thread (lane) per QP: the exact KKT point, or (solver ==
+// MM_QP_IPM) the iterate of cvxopt's interior-point algorithm with its status and iteration count (include/mm_qp.h)
+#if MM_TU <= 1
 __global__ void qp_kernel(int n, const double *__restrict__ G, const double *__restrict__ h,
-                          const int32_t *__restrict__ rows, double *__restrict__ u, uint8_t *status) {
+                          const int32_t *__restrict__ rows, int solver, double *__restrict__ u, uint8_t *status,
+                          int32_t *iters, int *err) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  const double a = G[(long long)k * 12], *hh = h + (long long)k * 4;
+  const double *g = G + (long long)k * 12, *hh = h + (long long)k * 4;
+  const int m = rows[k];
+  // only the G of get_G (cbf.py:288-304,386-403): [a 0 -1; 1 0 0; -1 0 0] (+ [a 0 -1])
+  bool ok = (m == 3 || m == 4) && g[1] == 0.0 && g[2] == -1.0 && g[3] == 1.0 && g[4] == 0.0 && g[5] == 0.0 && g[6] == -1.0 &&
+            g[7] == 0.0 && g[8] == 0.0;
+  if (ok && m == 4) ok = g[9] == g[0] && g[10] == 0.0 && g[11] == -1.0;
+  if (iters) iters[k] = 0;
+  if (!ok) {
+    u[k * 3 + 0] = u[k * 3 + 1] = u[k * 3 + 2] = __builtin_nan("");
+    if (status) status[k] = MM_QPS_BAD_STRUCTURE;
+    atomicOr(err, MM_LATCH_BAD_QP);
+    return;
+  }
+  const double a = g[0];
+  if (solver == MM_QP_IPM) {
+    double d, sl;
+    int it;
+    const int opt = mm_qp_ipm_cbf(a, hh[0], hh[1], hh[2], m == 4 ? hh[3] : 0.0, m, &d, &sl, &it);
+    u[k * 3 + 0] = d; u[k * 3 + 1] = 0.0; u[k * 3 + 2] = sl;
+    if (status) status[k] = opt ? MM_QPS_OPTIMAL : MM_QPS_UNKNOWN;
+    if (iters) iters[k] = it;
+    return;
+  }
   double hc = hh[0];
-  if (rows[k] == 4 && hh[3] < hc) hc = hh[3];
+  if (m == 4 && hh[3] < hc) hc = hh[3];
   double d;
   if (a > 0) d = fmin(0.0, hc / a);
   else if (a < 0) d = fmax(0.0, hc / a);
@@ -1667,10 +1724,10 @@ __global__ void qp_kernel(int n, const double *__restrict__ G, const double *__r
   d = fmin(fmax(d, -hh[2]), hh[1]);
   const double s = a * d - hc;
   u[k * 3 + 0] = d; u[k * 3 + 1] = 0.0; u[k * 3 + 2] = s > 0 ? s : 0.0;
-  if (status) status[k] = 1;
+  if (status) status[k] = MM_QPS_OPTIMAL;
 }
 
-#endif  // MM_TU != 2
+#endif  // MM_TU <= 1
 
 // ------------------------------------------------------------------------------------------------
 // host side: C ABI
@@ -1682,10 +1739,11 @@ struct MMHandle_ {
   MMStateLayout lay;
   long long first_env;
   double *metrics;
+  int *dev_err;  // device error latch (MM_LATCH_* bits): hipMalloc'd at create, polled by mm_poll_errors
   char err[256];
 };
 
-#if MM_TU != 2
+#if MM_TU <= 1
 static uint64_t align256(uint64_t x) { return (x + 255u) & ~(uint64_t)255u; }
 
 extern "C" int32_t mm_abi_version(void) { return MM_ABI_VERSION; }
@@ -1709,6 +1767,7 @@ static int check_cfg(const MMConfig *c, int N, char *err) {
       c->simulation_frequency / c->policy_frequency > 3) { snprintf(err, 256, "unsupported frequencies"); return MM_ERR_INVALID_ARG; }
   if (N > 12) { snprintf(err, 256, "N=%d exceeds the 6+6 spawn slots", N); return MM_ERR_INVALID_ARG; }
   if (c->n_hdv < 0 || c->n_hdv >= N) { snprintf(err, 256, "n_hdv=%d must leave at least one controlled vehicle of N=%d", c->n_hdv, N); return MM_ERR_INVALID_ARG; }
+  if (c->qp_solver != MM_QP_EXACT && c->qp_solver != MM_QP_IPM) { snprintf(err, 256, "unknown qp_solver %d", c->qp_solver); return MM_ERR_INVALID_ARG; }
   return MM_OK;
 }
 
@@ -1734,11 +1793,34 @@ extern "C" int32_t mm_create(const MMConfig *cfg, int32_t E, int32_t N, int32_t 
   hipError_t rc = hipSetDevice(device);
   if (rc == hipSuccess) rc = hipMemcpy(h->state + h->lay.seed_offset, tmp, (size_t)E * 8u, hipMemcpyHostToDevice);
   free(tmp);
-  if (rc != hipSuccess) { free(h); return MM_ERR_DEVICE; }
+  if (rc == hipSuccess) rc = hipMalloc((void **)&h->dev_err, sizeof(int));
+  if (rc == hipSuccess) rc = hipMemset(h->dev_err, 0, sizeof(int));
+  if (rc != hipSuccess) { if (h->dev_err) (void)hipFree(h->dev_err); free(h); return MM_ERR_DEVICE; }
   *out = h;
   return MM_OK;
 }
-extern "C" int32_t mm_destroy(MMHandle h) { free(h); return MM_OK; }
+extern "C" int32_t mm_destroy(MMHandle h) {
+  if (!h) return MM_OK;
+  // launches of this handle may still be in flight and they write its error latch: drain the device first
+  hipError_t rc = hipSetDevice(h->device);
+  if (rc == hipSuccess) rc = hipDeviceSynchronize();
+  if (h->dev_err) (void)hipFree(h->dev_err);
+  free(h);
+  return rc == hipSuccess ? MM_OK : MM_ERR_DEVICE;
+}
+// include/mm_abi.h: conditions the reference raises inside step(), latched by the kernels
+extern "C" int32_t mm_poll_errors(MMHandle h, MMStream stream) {
+  if (!h) return MM_ERR_INVALID_ARG;
+  int bits = 0;
+  hipError_t rc = hipStreamSynchronize((hipStream_t)stream);
+  if (rc == hipSuccess) rc = hipMemcpy(&bits, h->dev_err, sizeof bits, hipMemcpyDeviceToHost);
+  if (rc == hipSuccess && bits) rc = hipMemset(h->dev_err, 0, sizeof(int));
+  if (rc != hipSuccess) return hip_fail(h, rc, "error poll");
+  if (bits & MM_LATCH_QP_BOUNDS) { snprintf(h->err, sizeof h->err, "Error in QP. Invalid accceleration"); return MM_ERR_QP_BOUNDS; }
+  if (bits & MM_LATCH_BAD_ACTION) { snprintf(h->err, sizeof h->err, "an action is outside 0..4"); return MM_ERR_INVALID_ARG; }
+  if (bits & MM_LATCH_BAD_QP) { snprintf(h->err, sizeof h->err, "mm_shield_qp: G is not of the form get_G builds (cbf.py:288-304,386-403)"); return MM_ERR_INVALID_ARG; }
+  return MM_OK;
+}
 extern "C" int32_t mm_set_config(MMHandle h, const MMConfig *cfg) {
   if (!h) return MM_ERR_INVALID_ARG;
   int rc = check_cfg(cfg, h->N, h->err);
@@ -1751,7 +1833,7 @@ extern "C" int32_t mm_set_metrics_buffer(MMHandle h, double *metrics) {
   return MM_OK;
 }
 extern "C" const char *mm_last_error(MMHandle h) { return h ? h->err : "null handle"; }
-#endif  // MM_TU != 2
+#endif  // MM_TU <= 1
 
 static DevCfg dev_cfg(const MMHandle h) {
   const MMConfig &c = h->cfg;
@@ -1768,6 +1850,7 @@ static DevCfg dev_cfg(const MMHandle h) {
   d.rs_span2 = (d.rs_lo + (d.rs_hi - d.rs_lo) / 2) - d.rs_lo; d.rs_ispan2 = 1.0 / d.rs_span2;  // mrew, collaborating
   d.agent_reward = c.env_kind == MM_ENV_V1 ? c.agent_reward : 0;
   d.steer_vel = (c.env_kind == MM_ENV_V1 && c.lateral_control == MM_LATERAL_STEER_VEL) ? 1 : 0;
+  d.err = h->dev_err;
   return d;
 }
 static DevState dev_state(const MMHandle h) {
@@ -1779,7 +1862,7 @@ static DevState dev_state(const MMHandle h) {
 }
 static int group_size(int N) { return N <= 2 ? 2 : (N <= 4 ? 4 : (N <= 8 ? 8 : 16)); }
 
-#if MM_TU != 2
+#if MM_TU <= 1
 template <int G, int KIND>
 static void launch_reset_t(MMHandle h, int mode, const uint8_t *mask, const uint64_t *seeds, void *obs,
                            uint8_t *avail, hipStream_t s) {
@@ -1814,6 +1897,13 @@ static int launch_reset(MMHandle h, int mode, const uint8_t *mask, const uint64_
 extern "C" int32_t mm_reset(MMHandle h, const uint8_t *env_mask, const uint64_t *seeds, void *obs,
                             uint8_t *avail, MMStream stream) {
   if (!h) return MM_ERR_INVALID_ARG;
+  {  // each road has 6 spawn slots shared by its CAVs and HDVs (merge_env_v1.py:284-285; np.random.choice raises beyond)
+    const int n_hdv = h->cfg.n_hdv, n_cav = h->N - n_hdv, ramp = (n_cav - n_cav / 2) + (n_hdv - n_hdv / 2);
+    if (ramp > 6) {
+      snprintf(h->err, sizeof h->err, "%d CAVs + %d HDVs need %d ramp spawn slots, the road has 6", n_cav, n_hdv, ramp);
+      return MM_ERR_INVALID_ARG;
+    }
+  }
   return launch_reset(h, 0, env_mask, seeds, obs, avail, stream);
 }
 extern "C" int32_t mm_init_from_kinematics(MMHandle h, const uint8_t *env_mask, MMStream stream) {
@@ -1825,13 +1915,13 @@ extern "C" int32_t mm_observe(MMHandle h, void *obs, uint8_t *avail, MMStream st
   return launch_reset(h, 2, nullptr, nullptr, obs, avail, stream);
 }
 
-#endif  // MM_TU != 2
+#endif  // MM_TU <= 1
 
-template <int G, int KIND, int SHIELD, bool MIXED>
+template <int G, int KIND, int SHIELD, bool MIXED, bool IPM = false>
 static void launch_step_t(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   const long long threads = (long long)h->E * G;
   const unsigned grid = (unsigned)((threads + MM_STEP_BLOCK - 1) / MM_STEP_BLOCK);
-  hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, MIXED>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dev_cfg(h), dev_state(h),
+  hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, MIXED, IPM>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dev_cfg(h), dev_state(h),
                      actions, *out, h->metrics);
 }
 template <int G, bool MIXED>
@@ -1847,10 +1937,17 @@ static void launch_step_m(MMHandle h, const int32_t *actions, const MMStepOut *o
     default: launch_step_t<G, MM_ENV_V1, MM_SHIELD_NONE, MIXED>(h, actions, out, s);
   }
 }
-// mixed traffic (cfg.n_hdv > 0) runs the kernels that carry the IDM/MOBIL code; CAV-only batches
-// keep the leaner instantiation
+template <int G>
+static void launch_step_ipm_g(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+  if (h->cfg.shield == MM_SHIELD_MASS) launch_step_t<G, MM_ENV_V1, MM_SHIELD_MASS, true, true>(h, actions, out, s);
+  else launch_step_t<G, MM_ENV_V1, MM_SHIELD_HSS, true, true>(h, actions, out, s);
+}
+// mixed traffic (cfg.n_hdv > 0) and steer_vel run the "general" kernels that carry the IDM/MOBIL code; the MM_QP_IPM
+// fidelity mode has its own (general, literal-sweep) kernels; CAV-only batches keep the leaner instantiation.
+// In the split build the three families are separate translation units (Makefile).
 #if MM_TU != 0
 void mm_launch_step_general(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s);
+void mm_launch_step_ipm(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s);
 #endif
 #if MM_TU == 2
 void mm_launch_step_general(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
@@ -1861,13 +1958,29 @@ void mm_launch_step_general(MMHandle h, const int32_t *actions, const MMStepOut 
     default: launch_step_m<16, true>(h, actions, out, s); break;
   }
 }
+#elif MM_TU == 3
+void mm_launch_step_ipm(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+  switch (group_size(h->N)) {
+    case 2: launch_step_ipm_g<2>(h, actions, out, s); break;
+    case 4: launch_step_ipm_g<4>(h, actions, out, s); break;
+    case 8: launch_step_ipm_g<8>(h, actions, out, s); break;
+    default: launch_step_ipm_g<16>(h, actions, out, s); break;
+  }
+}
 #else
 template <int G>
 static void launch_step_g(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
 #ifdef MM_ONLY_MIXED  // tuning builds
   launch_step_m<G, MM_ONLY_MIXED>(h, actions, out, s);
 #else
-  if (h->cfg.n_hdv > 0 || (h->cfg.env_kind == MM_ENV_V1 && h->cfg.lateral_control == MM_LATERAL_STEER_VEL))
+  const bool shielded = h->cfg.env_kind == MM_ENV_V1 && h->cfg.shield != MM_SHIELD_NONE;
+  if (shielded && h->cfg.qp_solver == MM_QP_IPM)
+#if MM_TU == 1
+    mm_launch_step_ipm(h, actions, out, s);
+#else
+    launch_step_ipm_g<G>(h, actions, out, s);
+#endif
+  else if (h->cfg.n_hdv > 0 || (h->cfg.env_kind == MM_ENV_V1 && h->cfg.lateral_control == MM_LATERAL_STEER_VEL))
 #if MM_TU == 1
     mm_launch_step_general(h, actions, out, s);
 #else
@@ -1900,18 +2013,24 @@ extern "C" int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *
 }
 
 
-template <int G>
-static void launch_shield_g(MMHandle h, const double *as, const double *aa, double *ss, double *sa, uint8_t *stt,
-                            double *mg, hipStream_t s) {
+template <int G, bool IPM>
+static void launch_shield_gi(MMHandle h, const double *as, const double *aa, double *ss, double *sa, uint8_t *stt,
+                             double *mg, hipStream_t s) {
   const long long threads = (long long)h->E * G;
   const unsigned grid = (unsigned)((threads + 255) / 256);
   const int sh = h->cfg.env_kind == MM_ENV_V1 ? h->cfg.shield : MM_SHIELD_NONE;
   if (sh == MM_SHIELD_MASS)
-    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_MASS>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), as, aa, ss, sa, stt, mg);
+    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_MASS, IPM>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), as, aa, ss, sa, stt, mg);
   else if (sh == MM_SHIELD_HSS)
-    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_HSS>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), as, aa, ss, sa, stt, mg);
+    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_HSS, IPM>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), as, aa, ss, sa, stt, mg);
   else
-    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_NONE>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), as, aa, ss, sa, stt, mg);
+    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_NONE, false>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), as, aa, ss, sa, stt, mg);
+}
+template <int G>
+static void launch_shield_g(MMHandle h, const double *as, const double *aa, double *ss, double *sa, uint8_t *stt,
+                            double *mg, hipStream_t s) {
+  if (h->cfg.qp_solver == MM_QP_IPM) launch_shield_gi<G, true>(h, as, aa, ss, sa, stt, mg, s);
+  else launch_shield_gi<G, false>(h, as, aa, ss, sa, stt, mg, s);
 }
 extern "C" int32_t mm_shield_actions(MMHandle h, const double *act_steer, const double *act_acc, double *safe_steer,
                                      double *safe_acc, uint8_t *status, double *margin, MMStream stream) {
@@ -1928,17 +2047,21 @@ extern "C" int32_t mm_shield_actions(MMHandle h, const double *act_steer, const 
   }
 #endif
   hipError_t rc = hipGetLastError();
-  return rc == hipSuccess ? MM_OK : hip_fail(h, rc, "shield launch");
+  if (rc != hipSuccess) return hip_fail(h, rc, "shield launch");
+  // the reference call raises check_bounds' ValueError synchronously (only the IPM iterate can leave the bounds)
+  return h->cfg.qp_solver == MM_QP_IPM ? mm_poll_errors(h, stream) : MM_OK;
 }
 
 extern "C" int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec, const int32_t *rows,
-                                double *u_out, uint8_t *status, MMStream stream) {
-  if (n <= 0) return MM_OK;
-  hipLaunchKernelGGL(qp_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, G, hvec, rows, u_out,
-                     status);
+                                int32_t solver, double *u_out, uint8_t *status, int32_t *iters, MMStream stream) {
+  if (!h || n < 0 || (solver != MM_QP_EXACT && solver != MM_QP_IPM)) return MM_ERR_INVALID_ARG;
+  if (n == 0) return MM_OK;
+  if (!G || !hvec || !rows || !u_out) return MM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(qp_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, G, hvec, rows, (int)solver, u_out,
+                     status, iters, h->dev_err);
   hipError_t rc = hipGetLastError();
-  if (rc != hipSuccess) return h ? hip_fail(h, rc, "qp launch") : MM_ERR_DEVICE;
-  return MM_OK;
+  if (rc != hipSuccess) return hip_fail(h, rc, "qp launch");
+  return mm_poll_errors(h, stream);
 }
 
 // diagnostics: element-wise mm_math evaluation (CPU/GPU bit-equality tests)
@@ -2178,4 +2301,4 @@ extern "C" int32_t mm_debug_read_stamps(unsigned long long *out16, int32_t reset
   return rc == hipSuccess ? MM_OK : MM_ERR_DEVICE;
 }
 #endif
-#endif  // MM_TU != 2
+#endif  // MM_TU <= 1 (the #else of the general / ipm launchers)

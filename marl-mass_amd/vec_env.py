@@ -31,7 +31,7 @@ class BatchedMergeEnv(object):
 
     def __init__(self, clib, E, N, env_id="merge-multi-agent-v1", config=None, device="cpu",
                  cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0, first_env=0,
-                 trace=False, debug_flags=0, n_hdv=0):
+                 trace=False, debug_flags=0, n_hdv=0, qp_solver="exact"):
         self.clib, self.E, self.N = clib, int(E), int(N)
         self.env_id = env_id
         self.device = torch.device(device)
@@ -41,6 +41,7 @@ class BatchedMergeEnv(object):
         self.cbf_eta, self.cbf_tau = cbf_eta, cbf_tau
         self.auto_reset, self.obs_f64, self.seed = auto_reset, obs_f64, seed
         self.debug_flags = debug_flags
+        self.qp_solver = qp_solver  # "exact" (closed-form KKT point) | "ipm" (cvxopt's coneqp iterate, fidelity mode)
         self.n_hdv = int(n_hdv)  # device reset: the last n_hdv vehicles of every env are IDM/MOBIL HDVs
         self.n_f = 6 if env_id == "merge-multi-agent-v1" else 5
         self.n_s = 5 * self.n_f  # merge_env_v1.py:28 / :413
@@ -89,13 +90,13 @@ class BatchedMergeEnv(object):
     def _make_cfg(self):
         return abi.make_config(self.env_id, self.config, cbf_eta=self.cbf_eta, cbf_tau=self.cbf_tau,
                                auto_reset=self.auto_reset, obs_f64=self.obs_f64, seed=self.seed,
-                               debug_flags=self.debug_flags, n_hdv=self.n_hdv)
+                               debug_flags=self.debug_flags, n_hdv=self.n_hdv, qp_solver=self.qp_solver)
 
     def configure(self, config=None, **kw):
         """env.config[k] = v after construction (run_mappo.py:145-171); CBFType globals via kw."""
         if config:
             self.config.update(config)
-        for k in ("cbf_eta", "cbf_tau", "auto_reset", "seed", "n_hdv"):
+        for k in ("cbf_eta", "cbf_tau", "auto_reset", "seed", "n_hdv", "qp_solver"):
             if k in kw:
                 setattr(self, k, kw[k])
         self._cfg = self._make_cfg()
@@ -133,6 +134,9 @@ class BatchedMergeEnv(object):
         k8 = present.to(torch.uint8)
         if kind is not None:
             k8 = k8 * torch.as_tensor(kind, device=dev).view(self.E, self.N).to(torch.uint8)
+            if self.n_hdv == 0 and bool((k8 == 2).any()):
+                # the CAV-only kernels would drive such a vehicle as a CAV from actions[i]
+                raise ValueError("HDVs (kind == 2) in the spawn need mixed traffic: configure(n_hdv=...) > 0 first")
         put(self.u8[abi.B["KIND"]], k8)
         m = None if env_mask is None else env_mask.to(dev, torch.uint8).contiguous()
         self.clib.check(self.clib.lib.mm_init_from_kinematics(self._h, _ptr(m), self._stream()), self._h)
@@ -149,6 +153,7 @@ class BatchedMergeEnv(object):
         """MergeEnv.step (merge_env_v1.py:126-166) for every env; actions int32 [E, N] in 0..4.
         obs_out: optional caller buffer (same shape / dtype / device as self.obs, contiguous) the new
         observation is written to instead of self.obs -- a rollout hands over its states[t + 1] slot."""
+        abi.check_supervisor(self.config.get("safety_guarantee"))
         if actions.dtype != torch.int32 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(self.device, torch.int32).contiguous()
         assert actions.numel() == self.E * self.N
@@ -191,8 +196,14 @@ class BatchedMergeEnv(object):
         self.clib.check(self.clib.lib.mm_set_metrics_buffer(self._h, _ptr(self.metrics)), self._h)
         return self.metrics
 
-    def shield_qp(self, G, h, rows):
-        """Batched stand-alone shield QP (cbf.py:110-161): G [n,4,3], h [n,4], rows [n] -> u [n,3], status."""
+    def poll_errors(self):
+        """Raise what the reference would have raised from inside step() since the last poll: check_bounds'
+        ValueError (cbf.py:87-96) or an action outside 0..4.  Synchronises the stream (mm_poll_errors)."""
+        self.clib.check(self.clib.lib.mm_poll_errors(self._h, self._stream()), self._h)
+
+    def shield_qp(self, G, h, rows, solver=None, with_iters=False):
+        """Batched stand-alone shield QP (cbf.py:110-161): G [n,4,3], h [n,4], rows [n] -> u [n,3], status
+        (_cabi.QPS_*) [, IPM iterations].  solver: "exact" | "ipm" (default: this env's qp_solver)."""
         dev = self.device
         G = torch.as_tensor(G, dtype=torch.float64, device=dev).contiguous()
         h = torch.as_tensor(h, dtype=torch.float64, device=dev).contiguous()
@@ -200,9 +211,11 @@ class BatchedMergeEnv(object):
         n = rows.numel()
         u = torch.zeros(n, 3, dtype=torch.float64, device=dev)
         st = torch.zeros(n, dtype=torch.uint8, device=dev)
-        self.clib.check(self.clib.lib.mm_shield_qp(self._h, n, _ptr(G), _ptr(h), _ptr(rows), _ptr(u),
-                                                   _ptr(st), self._stream()), self._h)
-        return u, st
+        it = torch.zeros(n, dtype=torch.int32, device=dev)
+        sid = abi.qp_solver_id(self.qp_solver if solver is None else solver)
+        self.clib.check(self.clib.lib.mm_shield_qp(self._h, n, _ptr(G), _ptr(h), _ptr(rows), sid, _ptr(u),
+                                                   _ptr(st), _ptr(it), self._stream()), self._h)
+        return (u, st, it) if with_iters else (u, st)
 
     def shield_actions(self, act_steer, act_acc):
         """safety_layer(...) (decentral_layer.py:767-817) for every controlled vehicle on the current state,

@@ -93,6 +93,7 @@ typedef struct {
   double local_reward, regional_reward;
   /* trace of the last shield call */
   double qp_rows, qp_a, qp_h[4], qp_d, lc_margin;
+  int qp_optimal, qp_bounds;   /* sol["status"] != "unknown" (cbf.py:140); check_bounds would raise (cbf.py:87-96) */
   int lon_safe, lon_invariant; /* CBF_AV.update_status cbf.py:341-351 */
   double shield_headway;       /* vehicle.min_headway as the last shield call set it */
 } Veh;
@@ -112,6 +113,7 @@ struct MMHandle_ {
   int64_t first_env;
   double *metrics;
   char err[256];
+  int latched; /* error raised inside step(), reported by mm_poll_errors (the HIP twin cannot return it from a launch) */
 };
 
 /* ------------------------------------------------------------------ utils.py */
@@ -509,6 +511,177 @@ static int close_vehicles_to(const Env *e, int i, double distance, int count, in
 }
 
 /*
+ * cvxopt.solvers.qp (cbf.py:134) -> coneqp for dense P (diagonal here, cbf.py:40-44), q, G, h, no equality
+ * constraints, default options: a C restatement of the published interior-point algorithm (cvxopt
+ * documentation, "Cone Programming" / coneqp; Vandenberghe 2010) specialised to the 'l' cone, following
+ * the order of operations of tools/refshim/cvxopt/coneqp.py (the reference-side stand-in that made the
+ * ipm_* fixtures) line by line, so the two agree bit for bit.  cvxopt 1.2.7 itself is not installable
+ * in this image: "parity unpinned" against the real binary (BLAS/LAPACK rounding), pinned against the
+ * stand-in.  n = 3 unknowns, m = 3 | 4 rows.  Returns 1 "optimal" / 0 "unknown"; *iters = iterations.
+ */
+#define QP_N 3
+static double qp_dot(const double *a, const double *b, int n) {
+  double t = 0.0;
+  for (int i = 0; i < n; i++) t += a[i] * b[i];
+  return t;
+}
+typedef struct { double Gs[4][QP_N], L[QP_N][QP_N], di[4]; int m; } QpKkt;
+static int qp_factor(QpKkt *f, const double *Pd, const double G[4][QP_N], int m, const double *di) { /* misc.kkt_chol2 */
+  double S[QP_N][QP_N];
+  f->m = m;
+  for (int k = 0; k < m; k++) { f->di[k] = di[k]; for (int j = 0; j < QP_N; j++) f->Gs[k][j] = di[k] * G[k][j]; }
+  for (int i = 0; i < QP_N; i++) {
+    for (int j = 0; j <= i; j++) {
+      double t = 0.0;
+      for (int k = 0; k < m; k++) t += f->Gs[k][i] * f->Gs[k][j];
+      S[i][j] = t;
+    }
+    S[i][i] = S[i][i] + Pd[i];
+  }
+  for (int j = 0; j < QP_N; j++) {
+    double t = S[j][j];
+    for (int k = 0; k < j; k++) t -= f->L[j][k] * f->L[j][k];
+    if (!(t > 0.0)) return 0; /* potrf: ArithmeticError */
+    f->L[j][j] = sqrt(t);
+    for (int i = j + 1; i < QP_N; i++) {
+      t = S[i][j];
+      for (int k = 0; k < j; k++) t -= f->L[i][k] * f->L[j][k];
+      f->L[i][j] = t / f->L[j][j];
+    }
+  }
+  return 1;
+}
+static void qp_solve(const QpKkt *f, double *x, double *z) {
+  const int m = f->m;
+  for (int k = 0; k < m; k++) z[k] = z[k] * f->di[k];
+  for (int j = 0; j < QP_N; j++) {
+    double t = 0.0;
+    for (int k = 0; k < m; k++) t += f->Gs[k][j] * z[k];
+    x[j] = x[j] + t;
+  }
+  for (int j = 0; j < QP_N; j++) {
+    x[j] = x[j] / f->L[j][j];
+    for (int i = j + 1; i < QP_N; i++) x[i] = x[i] - x[j] * f->L[i][j];
+  }
+  for (int j = QP_N - 1; j >= 0; j--) {
+    double t = x[j];
+    for (int i = QP_N - 1; i > j; i--) t -= f->L[i][j] * x[i];
+    x[j] = t / f->L[j][j];
+  }
+  for (int k = 0; k < m; k++) {
+    double t = -z[k];
+    for (int j = 0; j < QP_N; j++) t += x[j] * f->Gs[k][j];
+    z[k] = t;
+  }
+}
+static double qp_maxneg(const double *a, int m) { /* misc.max_step, 'l' block */
+  double t = -a[0];
+  for (int k = 1; k < m; k++) if (-a[k] > t) t = -a[k];
+  return t;
+}
+static int qp_ipm(const double *Pd, const double *q, const double G[4][QP_N], const double *h, int m, double *x,
+                  int *iters_out) {
+  QpKkt kkt;
+  double s[4], z[4], d[4], di[4], lmbda[4], lmbdasq[4], rx[QP_N], rz[4], dx[QP_N], dz[4], ds[4], ws3[4];
+  const double resx0 = fmax(1.0, sqrt(qp_dot(q, q, QP_N))), resz0 = fmax(1.0, sqrt(qp_dot(h, h, m)));
+  for (int k = 0; k < m; k++) di[k] = 1.0;
+  if (!qp_factor(&kkt, Pd, G, m, di)) { x[0] = x[1] = x[2] = NAN; *iters_out = 0; return 0; } /* ValueError("Rank...") */
+  for (int j = 0; j < QP_N; j++) x[j] = -q[j];
+  for (int k = 0; k < m; k++) z[k] = h[k];
+  qp_solve(&kkt, x, z);
+  for (int k = 0; k < m; k++) s[k] = -z[k];
+  {
+    double nrm = sqrt(qp_dot(s, s, m)), ts = qp_maxneg(s, m);
+    if (ts >= -1e-8 * fmax(nrm, 1.0)) { const double a = 1.0 + ts; for (int k = 0; k < m; k++) s[k] = s[k] + a; }
+    nrm = sqrt(qp_dot(z, z, m));
+    double tz = qp_maxneg(z, m);
+    if (tz >= -1e-8 * fmax(nrm, 1.0)) { const double a = 1.0 + tz; for (int k = 0; k < m; k++) z[k] = z[k] + a; }
+  }
+  double gap = qp_dot(s, z, m);
+  for (int iters = 0; iters <= 100; iters++) {
+    for (int j = 0; j < QP_N; j++) rx[j] = q[j] + Pd[j] * x[j];
+    const double f0 = 0.5 * (qp_dot(x, rx, QP_N) + qp_dot(x, q, QP_N));
+    for (int j = 0; j < QP_N; j++) {
+      double t = 0.0;
+      for (int k = 0; k < m; k++) t += G[k][j] * z[k];
+      rx[j] = rx[j] + t;
+    }
+    const double resx = sqrt(qp_dot(rx, rx, QP_N));
+    for (int k = 0; k < m; k++) {
+      double t = s[k] - h[k];
+      for (int j = 0; j < QP_N; j++) t += x[j] * G[k][j];
+      rz[k] = t;
+    }
+    const double resz = sqrt(qp_dot(rz, rz, m));
+    const double pcost = f0, dcost = f0 + qp_dot(z, rz, m) - gap;
+    int have_rel = 0;
+    double relgap = 0;
+    if (pcost < 0.0) { relgap = gap / -pcost; have_rel = 1; }
+    else if (dcost > 0.0) { relgap = gap / dcost; have_rel = 1; }
+    const double pres = resz / resz0, dres = resx / resx0;
+    if ((pres <= 1e-7 && dres <= 1e-7 && (gap <= 1e-7 || (have_rel && relgap <= 1e-6))) || iters == 100) {
+      *iters_out = iters;
+      return iters == 100 ? 0 : 1;
+    }
+    if (iters == 0)
+      for (int k = 0; k < m; k++) { d[k] = sqrt(s[k] / z[k]); di[k] = 1.0 / d[k]; lmbda[k] = sqrt(s[k] * z[k]); }
+    for (int k = 0; k < m; k++) lmbdasq[k] = lmbda[k] * lmbda[k];
+    if (!qp_factor(&kkt, Pd, G, m, di)) { *iters_out = iters; return 0; } /* "Terminated (singular KKT matrix)" */
+    const double mu = gap / m;
+    double sigma = 0.0, eta = 0.0, step = 1.0;
+    for (int i = 0; i < 2; i++) {
+      for (int k = 0; k < m; k++) {
+        double t = 0.0;
+        if (i == 1) t = t - ws3[k];
+        t = t - lmbdasq[k];
+        ds[k] = t + sigma * mu;
+      }
+      for (int j = 0; j < QP_N; j++) dx[j] = (-1.0 + eta) * rx[j];
+      for (int k = 0; k < m; k++) dz[k] = (-1.0 + eta) * rz[k];
+      for (int k = 0; k < m; k++) { ds[k] = ds[k] / lmbda[k]; dz[k] = dz[k] - d[k] * ds[k]; } /* f4_no_ir */
+      qp_solve(&kkt, dx, dz);
+      for (int k = 0; k < m; k++) ds[k] = ds[k] - dz[k];
+      const double dsdz = qp_dot(ds, dz, m);
+      if (i == 0) for (int k = 0; k < m; k++) ws3[k] = ds[k] * dz[k];
+      for (int k = 0; k < m; k++) { ds[k] = ds[k] / lmbda[k]; dz[k] = dz[k] / lmbda[k]; }
+      const double ts = qp_maxneg(ds, m), tz = qp_maxneg(dz, m);
+      const double t = fmax(0.0, fmax(ts, tz));
+      if (t == 0) step = 1.0;
+      else if (i == 0) step = fmin(1.0, 1.0 / t);
+      else step = fmin(1.0, 0.99 / t);
+      if (i == 0) {
+        const double sg = fmin(1.0, fmax(0.0, 1.0 - step + dsdz / gap * (step * step)));
+        sigma = sg * sg * sg;
+        eta = 0.0;
+      }
+    }
+    for (int j = 0; j < QP_N; j++) x[j] = x[j] + step * dx[j];
+    for (int k = 0; k < m; k++) { /* updated iterates in the current scaling + misc.update_scaling */
+      ds[k] = (step * ds[k] + 1.0) * lmbda[k];
+      dz[k] = (step * dz[k] + 1.0) * lmbda[k];
+      ds[k] = sqrt(ds[k]);
+      dz[k] = sqrt(dz[k]);
+      d[k] = d[k] * ds[k] / dz[k];
+      di[k] = 1.0 / d[k];
+      lmbda[k] = ds[k] * dz[k];
+      s[k] = d[k] * lmbda[k];
+      z[k] = di[k] * lmbda[k];
+    }
+    gap = qp_dot(lmbda, lmbda, m);
+  }
+  return 0; /* not reached */
+}
+/* the shield's QP through the IPM: P = diag(1, 1, 1e18), q = 0, rows [a 0 -1; 1 0 0; -1 0 0; (a 0 -1)] (cbf.py:288-322,386-403) */
+static int qp_ipm_cbf(double a, const double *hh, int rows, double *d_out, int *iters) {
+  const double Pd[3] = {1.0, 1.0, 1e18}, q[3] = {0.0, 0.0, 0.0};
+  const double G[4][QP_N] = {{a, 0.0, -1.0}, {1.0, 0.0, 0.0}, {-1.0, 0.0, 0.0}, {a, 0.0, -1.0}};
+  double x[3];
+  const int ok = qp_ipm(Pd, q, G, hh, rows, x, iters);
+  *d_out = x[0];
+  return ok;
+}
+
+/*
  * safety_layer -> safe_action_hss / safe_action_mass (decentral_layer.py:290-518, :521-764,
  * :767-817) with multi_agent_state (:85-257) and the CBF rows of cbf.py:262-430.  The QP
  * (cbf.py:134, cvxopt) is solved by its exact KKT closed form.
@@ -643,17 +816,24 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
     rows = 4;
     hc = h3 < h0 ? h3 : h0;
   }
-  /* exact KKT solution of min 1/2(d^2 + e^2 + 1e18 s^2): see tools/refshim/cvxopt */
   double hi = h1, lo = -h2, d;
-  if (a > 0) d = fmin(0.0, hc / a);
-  else if (a < 0) d = fmax(0.0, hc / a);
-  else d = 0.0;
-  d = fmin(fmax(d, lo), hi);
+  veh->qp_optimal = 1;
+  if (cfg->qp_solver == MM_QP_IPM) { /* the iterate cvxopt's coneqp stops at (qp_ipm above) */
+    const double hh[4] = {h0, h1, h2, h3};
+    int iters;
+    veh->qp_optimal = qp_ipm_cbf(a, hh, rows, &d, &iters);
+  } else { /* exact KKT solution of min 1/2(d^2 + e^2 + 1e18 s^2): see tools/refshim/cvxopt */
+    if (a > 0) d = fmin(0.0, hc / a);
+    else if (a < 0) d = fmax(0.0, hc / a);
+    else d = 0.0;
+    d = fmin(fmax(d, lo), hi);
+  }
   double u_safe0 = u[0] + d, u_safe1;
   veh->qp_rows = rows; veh->qp_a = a; veh->qp_h[0] = h0; veh->qp_h[1] = h1; veh->qp_h[2] = h2;
   veh->qp_h[3] = h3; veh->qp_d = d;
   int rc = 0;
-  if (u_safe0 - 0.001 > v_max || u_safe0 + 0.001 < v_min) rc = MM_ERR_QP_BOUNDS; /* cbf.py:87-96 */
+  veh->qp_bounds = (u_safe0 - 0.001 > v_max || u_safe0 + 0.001 < v_min); /* cbf.py:87-96 */
+  if (veh->qp_bounds) rc = MM_ERR_QP_BOUNDS;
 
   { /* update_status (cbf.py:341-351) with u_status = [u_safe (QP), u_ll[2:]] */
     double hls_lon = px_lon + q_lon;
@@ -794,7 +974,8 @@ static int simulate(const MMConfig *cfg, Env *e, const int32_t *actions, double 
   int rc = 0, order[MM_MAX_AGENTS];
   for (int k = 0; k < nsub; k++) {
     if (e->time % nsub == 0) /* action_type.act(action): action.py:226-231 */
-      for (int i = 0; i < e->n_ctrl; i++) mdp_act(&e->v[i], actions[i], is_lc);
+      for (int i = 0; i < e->n_ctrl; i++) /* an action outside 0..4 (KeyError in the reference, latched by mm_step) acts as IDLE */
+        mdp_act(&e->v[i], (actions[i] < 0 || actions[i] >= MM_N_ACTIONS) ? 1 : actions[i], is_lc);
     sort_by_x_desc(e, order); /* road.act: front to back; HDVs read what earlier vehicles already decided */
     for (int r = 0; r < e->n; r++) {
       if (e->v[order[r]].kind == 2) idm_act(e, order[r]);
@@ -838,8 +1019,8 @@ static int simulate(const MMConfig *cfg, Env *e, const int32_t *actions, double 
         t[MM_T_QP_H2 * A] = v->qp_h[2]; t[MM_T_QP_H3 * A] = v->qp_h[3];
         t[MM_T_QP_D * A] = v->qp_d; t[MM_T_LC_MARGIN * A] = v->lc_margin;
         if (v->qp_rows > 0) {
-          t[MM_T_STATUS * A] = (double)(MM_ST_RAN | MM_ST_IS_OPTIMAL | (v->lon_safe ? MM_ST_IS_SAFE : 0) |
-                                        (v->lon_invariant ? MM_ST_IS_INVARIANT : 0));
+          t[MM_T_STATUS * A] = (double)(MM_ST_RAN | (v->qp_optimal ? MM_ST_IS_OPTIMAL : 0) | (v->lon_safe ? MM_ST_IS_SAFE : 0) |
+                                        (v->lon_invariant ? MM_ST_IS_INVARIANT : 0) | (v->qp_bounds ? MM_ST_QP_BOUNDS : 0));
           t[MM_T_HEADWAY * A] = v->shield_headway;
         }
       }
@@ -1192,6 +1373,7 @@ static int check_cfg(const MMConfig *c, int N, char *err) {
       c->simulation_frequency / c->policy_frequency > 3) { snprintf(err, 256, "unsupported frequencies"); return MM_ERR_INVALID_ARG; }
   if (N > 12) { snprintf(err, 256, "N=%d exceeds the 6+6 spawn slots", N); return MM_ERR_INVALID_ARG; }
   if (c->n_hdv < 0 || c->n_hdv >= N) { snprintf(err, 256, "n_hdv=%d must leave at least one controlled vehicle of N=%d", c->n_hdv, N); return MM_ERR_INVALID_ARG; }
+  if (c->qp_solver != MM_QP_EXACT && c->qp_solver != MM_QP_IPM) { snprintf(err, 256, "unknown qp_solver %d", c->qp_solver); return MM_ERR_INVALID_ARG; }
   return MM_OK;
 }
 
@@ -1221,6 +1403,14 @@ const char *mm_last_error(MMHandle h) { return h ? h->err : "null handle"; }
 int32_t mm_reset(MMHandle h, const uint8_t *env_mask, const uint64_t *seeds_in, void *obs,
                  uint8_t *avail, MMStream stream) {
   (void)stream;
+  if (!h) return MM_ERR_INVALID_ARG;
+  { /* each road has 6 spawn slots shared by its CAVs and HDVs (merge_env_v1.py:284-285; np.random.choice raises beyond) */
+    const int n_hdv = h->cfg.n_hdv, n_cav = h->N - n_hdv, ramp = (n_cav - n_cav / 2) + (n_hdv - n_hdv / 2);
+    if (ramp > 6) {
+      snprintf(h->err, sizeof h->err, "%d CAVs + %d HDVs need %d ramp spawn slots, the road has 6", n_cav, n_hdv, ramp);
+      return MM_ERR_INVALID_ARG;
+    }
+  }
   uint64_t *seeds = (uint64_t *)(h->state + h->lay.seed_offset);
 #pragma omp parallel for schedule(static)
   for (int64_t e_idx = 0; e_idx < h->E; e_idx++) {
@@ -1276,6 +1466,15 @@ int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStre
   const int64_t A = (int64_t)h->E * h->N;
   int rc_all = MM_OK;
   uint64_t *seeds = (uint64_t *)(h->state + h->lay.seed_offset);
+  { /* DiscreteMetaAction.act: self.actions[action] raises KeyError outside 0..4 (action.py:194-196) */
+    const uint8_t *kind = h->state + h->lay.u8_offset + (int64_t)MM_B_KIND * A;
+    for (int64_t i = 0; i < A; i++)
+      if (kind[i] == 1 && (actions[i] < 0 || actions[i] >= MM_N_ACTIONS)) {
+        h->latched = MM_ERR_INVALID_ARG;
+        snprintf(h->err, sizeof h->err, "action %d of agent %lld is outside 0..4", (int)actions[i], (long long)i);
+        break;
+      }
+  }
   if (out->trace)
     for (int64_t k = 0; k < 3 * (int64_t)MM_T_COUNT * A; k++) out->trace[k] = NAN;
   double m_sum[7] = {0}, m_min = INFINITY;
@@ -1287,7 +1486,7 @@ int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStre
     if (e.n_ctrl == 0) continue;
     e.steps += 1; /* abstract.py:457 */
     int rc = simulate(cfg, &e, actions + base, out->trace, A, base);
-    if (rc) {
+    if (rc) { /* check_bounds' ValueError (cbf.py:87-96): latched, reported by mm_poll_errors like the HIP twin */
 #pragma omp critical
       { rc_all = rc; snprintf(h->err, sizeof h->err, "Error in QP. Invalid accceleration (env %lld)", (long long)e_idx); }
     }
@@ -1348,7 +1547,16 @@ int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStre
     for (int k = 0; k < 7; k++) h->metrics[k] += m_sum[k];
     if (m_min < h->metrics[7]) h->metrics[7] = m_min;
   }
-  return rc_all;
+  if (rc_all != MM_OK && h->latched == MM_OK) h->latched = rc_all;
+  return MM_OK;
+}
+
+int32_t mm_poll_errors(MMHandle h, MMStream stream) {
+  (void)stream;
+  if (!h) return MM_ERR_INVALID_ARG;
+  const int rc = h->latched;
+  h->latched = MM_OK;
+  return rc;
 }
 
 int32_t mm_shield_actions(MMHandle h, const double *act_steer, const double *act_acc, double *safe_steer,
@@ -1382,8 +1590,8 @@ int32_t mm_shield_actions(MMHandle h, const double *act_steer, const double *act
       safe_steer[i] = steer; safe_acc[i] = acc;
       const int fl = w.v[a].flags;
       if (status)
-        status[i] = (uint8_t)(MM_ST_RAN | MM_ST_IS_OPTIMAL | (w.v[a].lon_safe ? MM_ST_IS_SAFE : 0) |
-                              (w.v[a].lon_invariant ? MM_ST_IS_INVARIANT : 0) |
+        status[i] = (uint8_t)(MM_ST_RAN | (w.v[a].qp_optimal ? MM_ST_IS_OPTIMAL : 0) | (w.v[a].lon_safe ? MM_ST_IS_SAFE : 0) |
+                              (w.v[a].lon_invariant ? MM_ST_IS_INVARIANT : 0) | (w.v[a].qp_bounds ? MM_ST_QP_BOUNDS : 0) |
                               ((fl & MM_FLAG_IS_LC_SAFE) ? MM_ST_IS_LC_SAFE : 0) |
                               ((fl & MM_FLAG_IS_COLLABORATING) ? MM_ST_IS_COLLABORATING : 0) |
                               ((fl & MM_FLAG_COLLABORATE_ADJ) ? MM_ST_COLLABORATE_ADJ : 0));
@@ -1393,11 +1601,38 @@ int32_t mm_shield_actions(MMHandle h, const double *act_steer, const double *act
   return rc_all;
 }
 
-int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec,
-                     const int32_t *rows, double *u_out, uint8_t *status, MMStream stream) {
-  (void)h; (void)stream;
+static int qp_structure_ok(const double *g, int rows) { /* the G of get_G (cbf.py:288-304,386-403) and no other */
+  if (rows != 3 && rows != 4) return 0;
+  int ok = g[1] == 0.0 && g[2] == -1.0 && g[3] == 1.0 && g[4] == 0.0 && g[5] == 0.0 && g[6] == -1.0 && g[7] == 0.0 &&
+           g[8] == 0.0;
+  if (rows == 4) ok = ok && g[9] == g[0] && g[10] == 0.0 && g[11] == -1.0;
+  return ok;
+}
+int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec, const int32_t *rows, int32_t solver,
+                     double *u_out, uint8_t *status, int32_t *iters, MMStream stream) {
+  (void)stream;
+  if (n < 0 || (n > 0 && (!G || !hvec || !rows || !u_out)) || (solver != MM_QP_EXACT && solver != MM_QP_IPM)) return MM_ERR_INVALID_ARG;
+  int bad = 0;
   for (int k = 0; k < n; k++) {
     const double *g = G + (int64_t)k * 12, *hh = hvec + (int64_t)k * 4;
+    if (iters) iters[k] = 0;
+    if (!qp_structure_ok(g, rows[k])) {
+      u_out[k * 3 + 0] = u_out[k * 3 + 1] = u_out[k * 3 + 2] = NAN;
+      if (status) status[k] = MM_QPS_BAD_STRUCTURE;
+      bad = 1;
+      continue;
+    }
+    if (solver == MM_QP_IPM) { /* the general dense algorithm on the G as given */
+      const double Pd[3] = {1.0, 1.0, 1e18}, q[3] = {0.0, 0.0, 0.0};
+      double Gm[4][QP_N] = {{0}}, x[3];
+      for (int r = 0; r < rows[k]; r++) for (int j = 0; j < QP_N; j++) Gm[r][j] = g[r * 3 + j];
+      int it;
+      const int ok = qp_ipm(Pd, q, Gm, hh, rows[k], x, &it);
+      u_out[k * 3 + 0] = x[0]; u_out[k * 3 + 1] = x[1]; u_out[k * 3 + 2] = x[2];
+      if (status) status[k] = ok ? MM_QPS_OPTIMAL : MM_QPS_UNKNOWN;
+      if (iters) iters[k] = it;
+      continue;
+    }
     double a = g[0], hc = hh[0];
     if (rows[k] == 4 && hh[3] < hc) hc = hh[3];
     double hi = hh[1], lo = -hh[2], d;
@@ -1407,7 +1642,11 @@ int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec,
     d = fmin(fmax(d, lo), hi);
     double s = a * d - hc;
     u_out[k * 3 + 0] = d; u_out[k * 3 + 1] = 0.0; u_out[k * 3 + 2] = s > 0 ? s : 0.0;
-    if (status) status[k] = 1;
+    if (status) status[k] = MM_QPS_OPTIMAL;
+  }
+  if (bad) {
+    if (h) snprintf(h->err, sizeof h->err, "mm_shield_qp: G is not of the form get_G builds (cbf.py:288-304,386-403)");
+    return MM_ERR_INVALID_ARG;
   }
   return MM_OK;
 }
@@ -1433,6 +1672,19 @@ int32_t mm_math_eval(int32_t fn, int32_t n, const double *x, const double *x2, d
 }
 
 /* ------------------------------------------------------------------ unit hooks for tests */
+/* include/mm_qp.h (the sparsity-specialised IPM the HIP kernels run) compiled for the host, so that the CPU
+ * suite can hold it against the general dense qp_ipm above on every recorded QP without a GPU. */
+#include "../include/mm_qp.h"
+int32_t orc_qp_ipm_header(int32_t n, const double *a, const double *hvec, const int32_t *rows, double *d, double *s,
+                          int32_t *iters, uint8_t *status) {
+  for (int k = 0; k < n; k++) {
+    int it;
+    const double *hh = hvec + (int64_t)k * 4;
+    status[k] = (uint8_t)mm_qp_ipm_cbf(a[k], hh[0], hh[1], hh[2], hh[3], rows[k], &d[k], &s[k], &it);
+    iters[k] = it;
+  }
+  return MM_OK;
+}
 /* Pure functions exposed so tests can pin them against tests/golden/units.npz. */
 int32_t orc_closest_lane(double x, double y, double h) { return closest_lane(x, y, h); }
 int32_t orc_next_lane(int32_t lane, double x, double y) { return next_lane(lane, x, y); }

@@ -55,7 +55,11 @@ def test_struct_sizes():
 def test_shield_dispatch_strings():
     """safe_controller.py:229-241 / decentral_layer.py:767-817 string dispatch."""
     f = abi.shield_from_safety_guarantee
-    assert f("none") == f("priority") == f("dmc") == abi.SHIELD_NONE
+    assert f("none") == f(None) == f("priority") == f("dmc") == abi.SHIELD_NONE  # no VEHICLE-level shield
+    for baseline in ("priority", "dmc"):  # abstract.py:460-464 action supervisors: out of scope, must not step silently
+        with pytest.raises(NotImplementedError):
+            abi.check_supervisor(baseline)
+    abi.check_supervisor("none"), abi.check_supervisor("cbf-cav")
     assert f("cbf-av") == f("cbf-avs") == f("cbf-avs_cint") == f("cbf-hss") == abi.SHIELD_HSS
     assert f("cbf-cav") == f("cbf-mass") == abi.SHIELD_MASS
     with pytest.raises(ValueError):
@@ -74,7 +78,7 @@ def test_product_path_refuses_cpu():
 def _create_rc(clib, E, N, device="cpu", **over):
     """mm_create's status for a given (E, N, config) with a correctly sized state buffer."""
     import torch
-    cfg = abi.make_config("merge-multi-agent-v1", abi.default_env_config("merge-multi-agent-v1"))
+    cfg = abi.make_config("merge-multi-agent-v1", dict(abi.default_env_config("merge-multi-agent-v1"), safety_guarantee="none"))
     for k, v in over.items():
         setattr(cfg, k, v)
     lay = abi.MMStateLayout()
@@ -101,6 +105,7 @@ def test_create_rejects_bad_sizes_and_configs():
     assert _create_rc(clib, 4, 8, n_hdv=8) != 0 and _create_rc(clib, 4, 8, n_hdv=-1) != 0
     assert _create_rc(clib, 4, 8, abi_version=abi.MM_ABI_VERSION + 1) != 0
     assert _create_rc(clib, 4, 8, shield=7) != 0
+    assert _create_rc(clib, 4, 8, qp_solver=abi.QP_IPM) == 0 and _create_rc(clib, 4, 8, qp_solver=2) != 0
 
 
 @pytest.mark.gpu
@@ -108,5 +113,6 @@ def test_create_rejects_bad_sizes_hip():
     from marl_mass_amd import hip_library
     clib = hip_library()
     assert _create_rc(clib, 4, 8, device="cuda") == 0
-    for E, N, over in ((0, 8, {}), (4, 0, {}), (4, 13, {}), (4, 8, {"n_hdv": 8}), (4, 8, {"abi_version": 1}), (4, 8, {"shield": 9})):
+    for E, N, over in ((0, 8, {}), (4, 0, {}), (4, 13, {}), (4, 8, {"n_hdv": 8}), (4, 8, {"abi_version": 1}), (4, 8, {"shield": 9}),
+                       (4, 8, {"qp_solver": 2})):
         assert _create_rc(clib, E, N, device="cuda", **over) != 0, (E, N, over)
