@@ -26,8 +26,14 @@ FLOAT_TOL = 1e-5  # north_star: "within 1e-5 on float state"
 def episode_files(pattern="*_*.npz"):
     """ep_*: random / idle tapes from reference spawns; sc_*: scripted crash scenarios (test/cbf);
     mx_*: mixed traffic (CAVs + IDM/MOBIL HDVs); rw_*: srew / mrew agent rewards; sl_*: with stand-alone
-    safety_layer probes; sv_*: lateral_control = "steer_vel"."""
-    return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern)) if os.path.basename(f)[:3] in ("ep_", "sc_", "mx_", "rw_", "sl_", "sv_"))
+    safety_layer probes; sv_*: lateral_control = "steer_vel"; ipm_*: `solvers.qp` answered by the coneqp
+    restatement (MM_QP_IPM mode); am_*: action masking on; ed_*: placed edge cases."""
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN, pattern))
+                  if os.path.basename(f).split("_")[0] in ("ep", "sc", "mx", "rw", "sl", "sv", "ipm", "am", "ed"))
+
+
+def is_ipm(meta):
+    return meta.get("qp_solver", "").startswith("coneqp")
 
 
 def load_episode(path):
@@ -38,10 +44,10 @@ def load_episode(path):
 
 def env_kwargs(meta):
     cfg = {"safety_guarantee": meta["shield"], "HEADWAY_TIME": meta["headway_time"],
-           "action_masking": False, "agent_reward": meta.get("agent_reward", "default"),
+           "action_masking": bool(meta.get("action_masking", False)), "agent_reward": meta.get("agent_reward", "default"),
            "lateral_control": meta.get("lateral_control", "steer")}
     return dict(env_id=meta["env_id"], config=cfg, cbf_eta=meta["eta"], cbf_tau=meta["headway_time"],
-                obs_f64=True, trace=True, n_hdv=meta.get("n_hdv", 0))
+                obs_f64=True, trace=True, n_hdv=meta.get("n_hdv", 0), qp_solver="ipm" if is_ipm(meta) else "exact")
 
 
 KNIFE_EDGE = 1e-9  # |LC margin| below this = the reference's own decision is rounding noise

@@ -50,9 +50,29 @@ def _gpu_env(E, N, **kw):
     return VecMergeEnv(E, N, device="cuda:0", **kw)
 
 
+PARITY_JSON = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "golden_parity_gpu.json")
+
+
+def _record_parity(name, err):
+    """Per-tape error maxima of the GPU replay, kept where the driver / gpurun pull them from (gpurun_out/)."""
+    os.makedirs(os.path.dirname(PARITY_JSON), exist_ok=True)
+    try:
+        with open(PARITY_JSON) as fh:
+            rows = json.load(fh)
+    except (OSError, ValueError):
+        rows = {}
+    rows[name] = {k: float(v) for k, v in err.items()}
+    with open(PARITY_JSON, "w") as fh:
+        json.dump(rows, fh, indent=1, sort_keys=True)
+
+
 @pytest.mark.parametrize("path", episode_files(), ids=lambda p: os.path.basename(p)[:-4])
 def test_golden_tape(path):
-    err = replay(_gpu_env, path, tol=1e-9, max_knife_edges=6)
+    """Every committed tape of the reference, teacher-forced, on the HIP path: floats within 1e-9, every discrete
+    quantity exact -- NO knife-edge allowance on the committed tapes (the count is asserted to be 0)."""
+    err = replay(_gpu_env, path, tol=1e-9, max_knife_edges=0)
+    assert err["knife_edges"] == 0
+    _record_parity(os.path.basename(path)[:-4], err)
     print(os.path.basename(path), json.dumps({k: float("%.3g" % v) for k, v in err.items()}))
 
 
@@ -204,11 +224,92 @@ def test_float32_obs_matches_float64():
 def test_shield_qp_entry_matches_golden(golden_dir):
     """mm_shield_qp on every (G, h) the reference assembled vs the exact-KKT u_bar in the tape."""
     z = np.load(os.path.join(golden_dir, "ep_v1_mass_N8_lc_s75.npz"))
-    env = _gpu_env(1, 2)
-    u, st = env.shield_qp(z["qp_G"], np.nan_to_num(z["qp_h"]), z["qp_rows"])
-    assert bool(st.all())
+    env = _gpu_env(1, 2, config={"safety_guarantee": "none"})
+    u, st = env.shield_qp(z["qp_G"], np.nan_to_num(z["qp_h"]), z["qp_rows"], solver="exact")
+    assert bool((st == abi.QPS_OPTIMAL).all())
     np.testing.assert_allclose(u.cpu().numpy()[:, 0], z["qp_x"][:, 0], rtol=0, atol=1e-12)
     np.testing.assert_allclose(u.cpu().numpy()[:, 2], z["qp_x"][:, 2], rtol=0, atol=1e-9)
+
+
+def test_shield_qp_ipm_bits_on_every_recorded_qp():
+    """MM_QP_IPM on the GPU (one QP per lane, include/mm_qp.h) on EVERY (G, h) the reference assembled in any tape:
+    d, s, status and iteration count equal, bit for bit, to what the reference-side coneqp stand-in returned
+    (qp_x of the ipm_* tapes, qp_x_alt of the others) -- and to the oracle's general dense IPM."""
+    from golden_util import is_ipm
+    Gs, hs, rs, xs, sts, its = [], [], [], [], [], []
+    for f in episode_files():
+        z, meta = load_episode(f)
+        if len(z["qp_rows"]) == 0:
+            continue
+        Gs.append(z["qp_G"]); hs.append(np.nan_to_num(z["qp_h"])); rs.append(z["qp_rows"])
+        xs.append(z["qp_x"] if is_ipm(meta) else z["qp_x_alt"]); sts.append(z["qp_status"]); its.append(z["qp_iters"])
+    G, h, rows = np.concatenate(Gs), np.concatenate(hs), np.concatenate(rs).astype(np.int32)
+    x_ref, st_ref, it_ref = np.concatenate(xs), np.concatenate(sts), np.concatenate(its)
+    assert len(rows) > 60000
+    env = _gpu_env(1, 2, config={"safety_guarantee": "none"})
+    u, st, it = env.shield_qp(G, h, rows, solver="ipm", with_iters=True)
+    u, st, it = u.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy()
+    assert np.array_equal(u[:, 0].view(np.int64), x_ref[:, 0].view(np.int64)), "d differs from the reference-side IPM"
+    assert np.array_equal(u[:, 2], x_ref[:, 2]) and np.array_equal(st, st_ref) and np.array_equal(it, it_ref)
+    cpu = oracle_env.OracleEnv(1, 2, config={"safety_guarantee": "none"})
+    uc, stc, itc = cpu.shield_qp(G, h, rows, solver="ipm", with_iters=True)
+    assert np.array_equal(uc.numpy()[:, 0], u[:, 0]) and np.array_equal(stc.numpy(), st) and np.array_equal(itc.numpy(), it)
+    print("IPM: %d QPs, %d 'unknown', iterations %d..%d" % (len(rows), int((st == 0).sum()), it.min(), it.max()))
+
+
+def test_shield_qp_rejects_foreign_structure():
+    """Only the G of get_G is supported (cbf.py:288-304,386-403): anything else is MM_ERR_INVALID_ARG, not a wrong answer."""
+    env = _gpu_env(1, 2, config={"safety_guarantee": "none"})
+    G = np.zeros((2, 4, 3)); G[:, 0] = (0.05, 0, -1); G[:, 1] = (1, 0, 0); G[:, 2] = (-1, 0, 0)
+    h = np.array([[1.0, 2.0, 2.0, 0.0]] * 2)
+    u, st = env.shield_qp(G, h, [3, 3], solver="exact")
+    assert bool((st == abi.QPS_OPTIMAL).all())
+    G[1, 0, 1] = 0.3  # a coupling with the steering variable the reference never builds
+    with pytest.raises(ValueError):
+        env.shield_qp(G, h, [3, 3], solver="exact")
+    env.shield_qp(G[:1], h[:1], [3], solver="ipm")  # the latch was cleared by the failed call
+
+
+IPM_CASES = [("cbf-cav", 8, 0, 256, 110), ("cbf-avs_cint", 4, 0, 256, 110), ("cbf-cav", 7, 3, 256, 110), ("cbf-avs_cint", 11, 0, 64, 60),
+             ("cbf-cav", 2, 0, 128, 60)]
+
+
+@pytest.mark.parametrize("safety,N,n_hdv,E,steps", IPM_CASES, ids=lambda c: str(c))
+def test_random_rollout_ipm_vs_oracle(safety, N, n_hdv, E, steps):
+    """MM_QP_IPM fidelity mode inside step(): the in-kernel interior-point QP (every vehicle, every sub-step) against the
+    oracle's general dense IPM, free-running with auto-reset, LC-heavy tape: every bit of state / obs / rewards, and the
+    per-sub-step status bits (is_optimal follows the IPM's status)."""
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5,
+              obs_f64=True, seed=2024, auto_reset=True, n_hdv=n_hdv, qp_solver="ipm", trace=True)
+    gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
+    gpu.reset(); cpu.reset()
+    g = torch.Generator().manual_seed(77)
+    p = torch.tensor([0.25, 0.3, 0.25, 0.1, 0.1])
+    for t in range(steps):
+        a = torch.multinomial(p, E * N, True, generator=g).view(E, N).int()
+        og, rg, dg, ig = gpu.step(a.cuda())
+        oc, rc, dc, ic = cpu.step(a)
+        assert torch.equal(gpu.u8.cpu(), cpu.u8) and torch.equal(gpu.env_i32.cpu(), cpu.env_i32), t
+        assert torch.equal(gpu.f64.cpu().nan_to_num(), cpu.f64.nan_to_num()), t
+        assert torch.equal(og.cpu(), oc) and torch.equal(rg.cpu(), rc) and torch.equal(dg.cpu(), dc), t
+        for plane in ("QP_ROWS", "QP_D", "STATUS", "SAFE_ACC"):  # the IPM's iterate, its status and what was integrated
+            k = abi.T[plane]
+            assert torch.equal(gpu.trace[:, k].cpu().nan_to_num(nan=-7.0), cpu.trace[:, k].nan_to_num(nan=-7.0)), (t, plane)
+    gpu.poll_errors(); cpu.poll_errors()  # check_bounds never fired
+
+
+def test_bad_action_is_latched():
+    """An action outside 0..4 is a KeyError inside the reference's step (action.py:194-196): mm_step cannot return it
+    from a launch, so it is latched and raised by poll_errors (the compat adapter polls after every step)."""
+    env = _gpu_env(4, 4, config={"safety_guarantee": "none"})
+    env.reset()
+    a = torch.ones(4, 4, dtype=torch.int32, device="cuda:0")
+    env.step(a); env.poll_errors()
+    a[2, 1] = 7
+    env.step(a)
+    with pytest.raises(ValueError):
+        env.poll_errors()
+    env.step(torch.ones(4, 4, dtype=torch.int32, device="cuda:0")); env.poll_errors()  # cleared
 
 
 def test_metrics_accumulator():

@@ -2,8 +2,9 @@
 """Generate golden input/output vectors from the REFERENCE (runs in the build container only).
 
 Imports hkbharath/MARL-MASS from /root/reference under the stand-ins in tools/refshim/
-(gym / pygame stubs, numpy+pandas compat, and a cvxopt stand-in whose `solvers.qp` is the exact
-KKT closed form -- cvxopt 1.2.7 is not installable here, see tools/refshim/cvxopt/__init__.py).
+(gym / pygame stubs, numpy+pandas compat, and a cvxopt stand-in -- cvxopt 1.2.7 is not installable
+here -- whose `solvers.qp` is either the exact KKT closed form or, for the ipm_* tapes, a restatement
+of cvxopt's own interior-point algorithm; see tools/refshim/cvxopt/__init__.py and coneqp.py).
 Everything else that runs is the reference's own arithmetic.  The outputs are DATA only
 (tests/golden/*.npz); no reference source is copied.
 
@@ -14,6 +15,9 @@ Fixture families
   reset.npz        reference reset() results for given seeds / vehicle counts
   ep_*.npz         episode tapes: initial state, action tape, per-sub-step vehicle state,
                    per-step obs / rewards / dones / info, and (shield runs) every QP (G, h, x)
+  ipm_*.npz        the same with `solvers.qp` answered by the coneqp restatement (MM_QP_IPM mode)
+  am_*.npz         action_masking = True (abstract.py:219-240,474-481, incl. the row aliasing)
+  ed_*.npz         placed edge cases: x < 0 terminal, |v| > 40 clamp, a <= 0 and lo > hi QPs
 """
 import os
 import sys
@@ -90,7 +94,8 @@ def _road_step_logged(self, dt):
 Road.step = _road_step_logged
 
 
-def make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=0, agent_reward="default", lateral_control="steer"):
+def make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=0, agent_reward="default", lateral_control="steer",
+             action_masking=False):
     """Mirror of how run_mappo.py:137-171 configures an env (values from the cited .ini files)."""
     CBFType.GAMMA_B = eta
     CBFType.TAU = headway_time
@@ -104,7 +109,7 @@ def make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=0, agent_reward="de
     env.config["HEADWAY_TIME"] = headway_time
     env.config["MERGING_LANE_COST"] = 4
     env.config["traffic_density"] = 1
-    env.config["action_masking"] = False
+    env.config["action_masking"] = bool(action_masking)
     env.config["safety_guarantee"] = shield
     env.config["lateral_control"] = lateral_control
     env.config["mixed_traffic"] = n_hdv > 0
@@ -116,15 +121,21 @@ def make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=0, agent_reward="de
 
 
 def _place_vehicles(env, placement):
-    """Replace the spawned vehicles by a scripted scenario: [(x, y, speed), ...] in creation order
+    """Replace the spawned vehicles by a scripted scenario: [(x, y, speed[, heading]), ...] in creation order
     (the way test/cbf/cbf_test_env.py:126-160,240-268 builds its fixed scenarios)."""
     road = env.road
     road.vehicles, env.controlled_vehicles = [], []
-    for k, (x, y, speed) in enumerate(placement):
+    for k, row in enumerate(placement):
+        x, y, speed = row[:3]
         v = env._make_ego_vehicle(road=road, position=np.array([x, y], dtype=float), speed=speed, veh_id=k)
+        if len(row) > 3:  # Vehicle.__init__(heading=...) (kinematics.py:36-53): lane index from the heading too
+            v.heading = float(row[3])
+            v.lane_index = road.network.get_closest_lane_index(v.position, v.heading)
+            v.lane = road.network.get_lane(v.lane_index)
+            v.target_lane_index = v.lane_index
         env.controlled_vehicles.append(v)
         road.vehicles.append(v)
-    env._record_vehicle_count(n_merge=sum(1 for (_, y, _) in placement if y > 5))
+    env._record_vehicle_count(n_merge=sum(1 for row in placement if row[1] > 5))
     env.define_spaces()
     obs = env.observation_type.observe()
     return np.asarray(obs).reshape((len(obs), -1))
@@ -156,12 +167,13 @@ def _probe_safety_layer(env, shield, t, rng):
 
 def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta, p=None,
                 max_steps=100, scripted=None, placement=None, n_hdv=0, agent_reward="default", probe_shield=False,
-                lateral_control="steer"):
+                lateral_control="steer", qp="exact", action_masking=False):
     global _SUBSTEP_LOG
     if ONLY and not any(name.startswith(o) for o in ONLY):
         return None
+    cvxopt.solvers.mode = qp  # "exact" | "coneqp" (tools/refshim/cvxopt)
     env = make_env(env_id, shield, n_cav, headway_time, eta, n_hdv=n_hdv, agent_reward=agent_reward,
-                   lateral_control=lateral_control)
+                   lateral_control=lateral_control, action_masking=action_masking)
     obs0, mask0 = env.reset(is_training=False, testing_seeds=seed)
     if placement is not None:
         obs0 = _place_vehicles(env, placement)
@@ -211,19 +223,27 @@ def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta,
         t += 1
     qps = cvxopt.solvers.log
     cvxopt.solvers.log = None
-    qp_rows = np.array([g.shape[0] for g, _, _ in qps], dtype=np.int32)
+    qp_rows = np.array([q_[0].shape[0] for q_ in qps], dtype=np.int32)
     qp_G = np.zeros((len(qps), 4, 3))
     qp_h = np.full((len(qps), 4), np.nan)
-    qp_x = np.zeros((len(qps), 3))
-    for k, (g, h, x) in enumerate(qps):
+    qp_x = np.zeros((len(qps), 3))        # what solvers.qp returned (the mode in meta["qp_solver"])
+    qp_x_alt = np.zeros((len(qps), 3))    # the other mode's answer to the same (G, h)
+    qp_status = np.zeros(len(qps), dtype=np.uint8)   # coneqp: 1 "optimal" / 0 "unknown"
+    qp_iters = np.zeros(len(qps), dtype=np.int32)    # coneqp iterations
+    for k, (g, h, x, x_alt, status, iters) in enumerate(qps):
         qp_G[k, :g.shape[0]] = g
         qp_h[k, :h.shape[0]] = h
         qp_x[k] = x
+        qp_x_alt[k] = x_alt
+        qp_status[k] = status == "optimal"
+        qp_iters[k] = iters
     meta = dict(name=name, env_id=env_id, shield=shield, n=n_cav, n_hdv=n_hdv, agent_reward=agent_reward,
                 lateral_control=lateral_control, seed=seed, tape_seed=tape_seed,
                 headway_time=headway_time, eta=eta, n_merge=int(env.n_merge),
-                n_s=int(env.n_s), crashed=bool(env.is_crashed()), steps=t,
-                qp_solver="exact-KKT closed form (cvxopt 1.2.7 unavailable)")
+                n_s=int(env.n_s), crashed=bool(env.is_crashed()), steps=t, action_masking=bool(action_masking),
+                qp_solver=("exact-KKT closed form (cvxopt 1.2.7 unavailable)" if qp == "exact" else
+                           "coneqp restatement of cvxopt's interior-point algorithm (cvxopt 1.2.7 unavailable)"))
+    cvxopt.solvers.mode = "exact"
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
         meta=json.dumps(meta),
@@ -239,7 +259,7 @@ def run_episode(name, env_id, shield, n_cav, seed, tape_seed, headway_time, eta,
         average_speed=np.array(rec["average_speed"]), traffic_speed=np.array(rec["traffic_speed"]),
         min_headway=np.array(rec["min_headway"]), merge_percent=np.array(rec["merge_percent"]),
         action_mask=np.array(rec["action_mask"]), qp_count=np.array(rec["qp_count"], dtype=np.int32),
-        qp_rows=qp_rows, qp_G=qp_G, qp_h=qp_h, qp_x=qp_x,
+        qp_rows=qp_rows, qp_G=qp_G, qp_h=qp_h, qp_x=qp_x, qp_x_alt=qp_x_alt, qp_status=qp_status, qp_iters=qp_iters,
         # MDPLCVehicle.steering_angle after every sub-step (non-zero only under lateral_control="steer_vel")
         **({"sub_sa": np.array(sub_sa)} if lateral_control != "steer" else {}),
         # control-profile tail per sub-step: [shield ran, is_optimal, is_safe, is_invariant, headway]
@@ -467,6 +487,45 @@ def main():
     metas.append(run_episode("sv_v1_hss_N4_s25", v1, "cbf-avs_cint", 4, 25, 62, 0.5, 0.03125, p=lc2, lateral_control="steer_vel"))
     metas.append(run_episode("sv_v1_mass_N8_s50", v1, "cbf-cav", 8, 50, 63, 0.5, 0.03125, p=lc2, lateral_control="steer_vel"))
     metas.append(run_episode("sv_v1_mass_3c3h_s75", v1, "cbf-cav", 3, 75, 64, 0.5, 0.03125, p=lc2, n_hdv=3, lateral_control="steer_vel"))
+    # (8) MM_QP_IPM fidelity mode: `solvers.qp` answered by the coneqp restatement (tools/refshim/cvxopt/coneqp.py)
+    ipm = dict(qp="coneqp")
+    metas.append(run_episode("ipm_v1_mass_N8_s0", v1, "cbf-cav", 8, 0, 200, 0.5, 0.03125, **ipm))
+    metas.append(run_episode("ipm_v1_mass_N8_lc_s75", v1, "cbf-cav", 8, 75, 5, 0.5, 0.03125, p=lc, **ipm))
+    metas.append(run_episode("ipm_v1_mass_N4_s25", v1, "cbf-cav", 4, 25, 148, 0.5, 0.03125, **ipm))
+    metas.append(run_episode("ipm_v1_hss_N4_s50", v1, "cbf-avs_cint", 4, 50, 173, 0.5, 0.03125, **ipm))
+    metas.append(run_episode("ipm_v1_hss_N8_lc_s0", v1, "cbf-avs_cint", 8, 0, 6, 0.5, 0.03125, p=lc, **ipm))
+    metas.append(run_episode("ipm_v1_mass_N11_s100", v1, "cbf-cav", 11, 100, 9, 0.5, 0.03125, **ipm))
+    metas.append(run_episode("ipm_v1_mass_4c3h_s25", v1, "cbf-cav", 4, 25, 66, 0.5, 0.03125, n_hdv=3, **ipm))
+    metas.append(run_episode("ipm_v1_mass_mrew_N8_s25", v1, "cbf-cav", 8, 25, 78, 0.5, 0.03125, p=lc2, agent_reward="mrew", **ipm))
+    metas.append(run_episode("ipm_sl_v1_mass_N8_s25", v1, "cbf-cav", 8, 25, 92, 0.5, 0.03125, p=lc2, probe_shield=True, **ipm))
+    for sname in ("lonx", "merge"):  # slack-active / "unknown"-status QPs live in the hard-braking scenarios
+        placement, script = scen[sname]
+        for tag, shield in (("hss", "cbf-avs_cint"), ("mass", "cbf-cav")):
+            metas.append(run_episode("ipm_sc_%s_%s" % (sname, tag), v1, shield, len(placement), 0, 0, 0.5, 0.03125,
+                                     scripted=script, placement=placement, **ipm))
+    # (9) action masking ON (abstract.py:219-240 _get_available_actions, :200-207,474-481 incl. the `[[0]*n_a]*n` aliasing:
+    # every row of the returned mask is the same list object, so each agent's row is the OR over all agents)
+    metas.append(run_episode("am_v0_none_N4_s0", v0, "none", 4, 0, 301, 1.2, 0.0, p=lc, action_masking=True))
+    metas.append(run_episode("am_v0_none_N8_s25", v0, "none", 8, 25, 302, 1.2, 0.0, p=lc2, action_masking=True))
+    metas.append(run_episode("am_v1_mass_N8_s50", v1, "cbf-cav", 8, 50, 303, 0.5, 0.03125, p=lc, action_masking=True))
+    metas.append(run_episode("am_v1_hss_3c3h_s75", v1, "cbf-avs_cint", 3, 75, 304, 0.5, 0.03125, p=lc2, n_hdv=3, action_masking=True))
+    # (10) placed edge cases the random tapes never reach
+    I = A["IDLE"]
+    #  x < 0 terminal (merge_env_v1.py:168-178): a vehicle rolling backwards across the start of the road
+    metas.append(run_episode("ed_v0_xneg", v0, "none", 2, 0, 0, 1.2, 0.0, scripted=[(I, I)], placement=[(0.3, 0.0, -6.0), (80.0, 0.0, 25.0)]))
+    metas.append(run_episode("ed_v1_xneg_none", v1, "none", 2, 0, 0, 0.5, 0.0, scripted=[(I, I)], placement=[(0.3, 0.0, -8.0), (90.0, 0.0, 25.0)]))
+    #  |v| > MAX_SPEED clamp of clip_actions (kinematics.py:143-152), without and with the shields
+    fast = [(60.0, 0.0, 46.0), (160.0, 0.0, 44.5), (40.0, 10.5, 43.0)]
+    for tag, shield in (("none", "none"), ("hss", "cbf-avs_cint"), ("mass", "cbf-cav")):
+        metas.append(run_episode("ed_v1_fast_%s" % tag, v1, shield, 3, 0, 0, 0.5, 0.03125, max_steps=12,
+                                 scripted=[(A["FASTER"], I, A["FASTER"])], placement=fast))
+    metas.append(run_episode("ed_v0_fast", v0, "none", 3, 0, 0, 1.2, 0.0, max_steps=12, scripted=[(A["FASTER"], I, A["FASTER"])], placement=fast))
+    #  QP corner branches: a = g.vx dt <= 0 (a vehicle pointing backwards: cos(heading + beta) < 0) and lo > hi
+    #  (negative speed under MASS: v_min = max(0, .) > v_max) -- exact mode only, the IPM has no answer to pin there
+    odd = [(150.0, 0.0, 12.0, 3.05), (200.0, 0.0, 20.0, 0.0), (120.0, 0.0, -3.0, 0.0), (90.0, 0.0, 24.0, 0.0)]
+    for tag, shield in (("hss", "cbf-avs_cint"), ("mass", "cbf-cav")):
+        metas.append(run_episode("ed_v1_odd_%s" % tag, v1, shield, 4, 0, 0, 0.5, 0.03125, max_steps=8,
+                                 scripted=[(I, I, I, A["FASTER"])], placement=odd))
     # the index is rebuilt from the tapes on disk, so a partial regeneration (`only <prefix> ...`) keeps the rest
     import glob
     metas = []
