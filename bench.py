@@ -5,11 +5,21 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one fused HIP launch = one policy step (3 simulation sub-steps + rewards + obs +
-auto-reset) of EVERY env of the rank.  Workload (config.workload): 65 536 envs x 8 CAVs per GPU,
+auto-reset) of EVERY env of the rank.  Workload (config.workload): 65 536 envs x 8 CAVs,
 merge-multi-agent-v1, safety_guarantee=cbf-cav (MASS), eta=0.03125, tau=0.5, synthetic episodes
 from the device RNG and a pre-generated categorical action tape.  Envs are independent,
-so ranks shard the batch with no data-path collective ("scaling": "weak", per-GPU work fixed);
-the only RCCL traffic is the 8-double metric all-reduce after the timed region.
+so ranks shard the batch with no data-path collective; the only RCCL traffic is the 8-double metric
+all-reduce after the timed region.
+
+Scaling modes (the line says which one ran, in `scaling`, `metric` and `config.workload`):
+  --scaling weak   (default) every rank holds --envs (65 536) envs: BASELINE's metric config on ONE GPU,
+                   replicated per GPU -- per-GPU work fixed as N grows;
+  --scaling strong --total-envs (65 536) envs are split over the ranks: at 8 ranks this is BASELINE.json
+                   config 5 exactly (8 192 envs per GPU) -- total work fixed.
+
+The batch is made STATIONARY before anything is timed: episode phases are staggered over the batch
+(env e starts at step (37 e) mod 100) and one untimed episode length is rolled, so every timed window --
+however short -- samples all phases of an episode incl. the merge zone and the in-kernel auto-reset.
 """
 import argparse
 import json
@@ -49,8 +59,21 @@ def cpu_baseline(args, env_id, cfg, kw):
     for t in range(K):
         env.step(acts[t % 8])
     dt = time.perf_counter() - t0
-    return {"value": E * N * K / dt, "unit": "agent-steps/s", "cores": int(threads), "kind": "port",
-            "sample": "%d envs x %d CAVs x %d steps, same config, OpenMP over envs (%.1f s)" % (E, N, K, dt)}
+    out = {"value": E * N * K / dt, "unit": "agent-steps/s", "cores": int(threads), "kind": "port",
+           "sample": "%d envs x %d CAVs x %d steps, same config, OpenMP over envs (%.1f s)" % (E, N, K, dt)}
+    # the reference's OWN Python path cannot travel to this box; its timing is regenerated in the build container by
+    # tools/time_reference.py and committed as profiles/reference_cpu.json (host, cores and stand-in caveats inside)
+    try:
+        ref = json.load(open(os.path.join(REPO, "profiles", "reference_cpu.json")))
+        row = [r for r in ref["rows"] if r["safety_guarantee"] == cfg["safety_guarantee"] and r["n_cav"] == N and r["qp_stand_in"] == "exact"]
+        if row:
+            out["reference_python"] = {"value": row[0]["agent_steps_per_s"], "unit": "agent-steps/s", "cores": 1,
+                                       "ms_per_env_step": row[0]["ms_per_env_step"], "host": ref["host"]["cpu_model"],
+                                       "where": "build container (not this box), tools/time_reference.py -> profiles/reference_cpu.json",
+                                       "caveat": "reference imported under stand-ins; QP by the closed form (cvxopt unavailable)"}
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
 
 
 def main():
@@ -58,7 +81,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--envs", type=int, default=65536, help="envs PER GPU")
+    ap.add_argument("--envs", type=int, default=65536, help="envs PER GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--total-envs", type=int, default=65536, help="envs over ALL GPUs (strong scaling; BASELINE c5 = 65536 over 8)")
+    ap.add_argument("--qp-solver", choices=("exact", "ipm"), default="exact",
+                    help="exact: closed-form KKT point (production); ipm: cvxopt's interior-point iterate (fidelity mode)")
+    ap.add_argument("--no-stagger", action="store_true", help="skip the phase staggering + pre-roll (lock-stepped episodes)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank REHEARSAL on a 1-GPU box: every rank uses cuda:0 and the collectives run over gloo "
+                         "(RCCL refuses two ranks on one device); exercises launcher / sharding / reduction, not xGMI")
     ap.add_argument("--agents", type=int, default=8)
     ap.add_argument("--shield", choices=sorted(SHIELDS), default="mass")
     ap.add_argument("--env-id", default="merge-multi-agent-v1")
@@ -75,24 +106,35 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    nccl = world > 1 and not args.rehearse_on_one_gpu
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if nccl:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" IS RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     here = os.path.dirname(os.path.abspath(__file__))
     if rank == 0 and not os.path.exists(os.path.join(here, "marl-mass_amd", "csrc", "libmm_hip.so")):
         import __graft_entry__  # fresh checkout: the library is a build artefact
         __graft_entry__.build()
     if world > 1:
-        dist.barrier(device_ids=[local])
-    from marl_mass_amd import VecMergeEnv, reduce_rollout_metrics
-    E, N = args.envs, args.agents
+        dist.barrier(device_ids=[local]) if nccl else dist.barrier()
+    from marl_mass_amd import VecMergeEnv, reduce_rollout_metrics, shard_range, _cabi as abi
+    N = args.agents
+    if args.scaling == "strong":
+        first_env, E = shard_range(args.total_envs, rank, world)
+        E_total = args.total_envs
+    else:
+        first_env, E, E_total = rank * args.envs, args.envs, args.envs * world
     cfg = {"safety_guarantee": SHIELDS[args.shield], "HEADWAY_TIME": 0.5 if args.shield != "none" else 1.2}
     kw = dict(cbf_eta=0.03125 if args.shield != "none" else 0.0, cbf_tau=cfg["HEADWAY_TIME"], seed=1000,
-              auto_reset=True, obs_f64=args.obs_f64, n_hdv=args.hdv)
-    env = VecMergeEnv(E, N, env_id=args.env_id, config=cfg, device=dev, first_env=rank * E, **kw)
+              auto_reset=True, obs_f64=args.obs_f64, n_hdv=args.hdv, qp_solver=args.qp_solver)
+    env = VecMergeEnv(E, N, env_id=args.env_id, config=cfg, device=dev, first_env=first_env, **kw)
     metrics = env.enable_metrics()
     env.reset()
     g = torch.Generator(device=dev).manual_seed(123 + rank)
@@ -101,7 +143,16 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local])
+            dist.barrier(device_ids=[local]) if nccl else dist.barrier()
+
+    if not args.no_stagger:
+        # stationary batch: stagger the episode phases by GLOBAL env id, then roll one episode length untimed so
+        # that every env has re-spawned once at its own phase and its state is consistent with its step counter
+        T = env.T
+        ge = torch.arange(first_env, first_env + E, dtype=torch.int64, device=dev)
+        env.env_i32[abi.EP["STEPS"]] = ((ge * 37) % T).to(torch.int32)
+        for t in range(T):
+            env.step(ring[t % 16])
 
     for t in range(args.warmup):
         env.step(ring[t % 16])
@@ -121,7 +172,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # HIP events on the launch stream
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if nccl or world == 1 else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         # end-of-rollout metric reduction: the only collective of the path
@@ -130,7 +181,7 @@ def main():
     m = metrics.cpu().tolist()
 
     if rank == 0:
-        agent_steps = float(E) * N * args.steps * world
+        agent_steps = float(E_total) * N * args.steps
         b_alg = algorithmic_bytes_per_agent_step(args.env_id, N)
         achieved = E * N * b_alg / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed PMC passes (profiles/traffic.json, written from
@@ -147,7 +198,7 @@ def main():
         # SQ_INSTS_VALU pass x 4 issue cycles per wave64 instruction, against 1024 SIMDs at the 2.4 GHz peak clock
         valu = None
         try:
-            sj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "step_kernel_summary.json")))
+            sj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tj.get("summary", "r01/step_kernel_summary.json"))))
             if traffic is not None:
                 n_valu = sj["pmc_per_launch"]["SQ_INSTS_VALU"] / sj["pmc_per_launch"]["SQ_WAVES"] * (E * 8 // 64 if N <= 8 else E * 16 // 64)
                 ach = n_valu * 4 / (kern_ms * 1e-3) / 1e12
@@ -155,21 +206,35 @@ def main():
                         "frac": ach / (1024 * 2.4e9 / 1e12), "valu_insts_per_wave": sj["pmc_per_launch"]["SQ_INSTS_VALU"] / sj["pmc_per_launch"]["SQ_WAVES"]}
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass
+        headline = args.shield == "mass" and not args.hdv and args.env_id.endswith("v1") and N == 8 and args.qp_solver == "exact"
+        if headline and E_total == 65536:
+            # BASELINE.json's metric on its own config: 65 536 envs x 8 CAVs in total (1 GPU weak == c5's batch on one GPU;
+            # 8 GPUs strong == c5 itself)
+            metric = "agent-steps/sec (whole node), MASS CBF shield on, 65536 envs x 8 CAVs"
+        elif headline:
+            metric = "agent-steps/sec (whole node), MASS CBF shield on, %d x 65536 envs x 8 CAVs (weak scaling: BASELINE's batch per GPU)" % world \
+                if (args.scaling == "weak" and E == 65536) else \
+                "agent-steps/sec (whole node), MASS CBF shield on, %d envs x 8 CAVs" % E_total
+        else:
+            metric = "agent-steps/sec (whole node), shield=%s, qp=%s, %d envs x %d vehicles" % (args.shield, args.qp_solver, E_total, N)
         line = {
-            "metric": "agent-steps/sec (whole node), MASS CBF shield on, 65536 envs x 8 CAVs" if (args.shield == "mass" and not args.hdv)
-                      else "agent-steps/sec (whole node), shield=%s" % args.shield,
+            "metric": metric,
             "value": agent_steps / elapsed, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d envs x %d CAVs per GPU, %s, safety_guarantee=%s, eta=0.03125, tau=%.1f, "
-                                   "100-step episodes with auto-reset, categorical action tape%s"
-                                   % (E, N, args.env_id, cfg["safety_guarantee"], cfg["HEADWAY_TIME"],
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d envs x %d CAVs in total = %d per GPU on %d GPU(s) (%s scaling), %s, safety_guarantee=%s, "
+                                   "qp_solver=%s, eta=0.03125, tau=%.1f, 100-step episodes with in-kernel auto-reset, episode "
+                                   "phases staggered over the batch%s, categorical action tape p=[.1,.6,.1,.1,.1]%s"
+                                   % (E_total, N, E, world, args.scaling, args.env_id, cfg["safety_guarantee"], args.qp_solver,
+                                      cfg["HEADWAY_TIME"], " (OFF)" if args.no_stagger else "",
                                       (", of which %d HDVs per env" % args.hdv) if args.hdv else ""),
-                       "envs_per_gpu": E, "agents": N, "obs_dtype": "f64" if args.obs_f64 else "f32",
+                       "envs_total": E_total, "envs_per_gpu": E, "agents": N, "obs_dtype": "f64" if args.obs_f64 else "f32",
+                       "qp_solver": args.qp_solver,
                        "parallelism": "env-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/)",
+                         "traffic_unit": "bytes/launch: rocprofv3 PMC passes of this command, 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction), "
+                                         "committed under profiles/ (see profiles/traffic.json: source)",
                          "alg_bytes_per_launch": E * N * b_alg,
                          "kernel": "step_kernel", "kernel_ms": kern_ms, "alg_bytes_per_agent_step": b_alg},
             "rollout_metrics": {"mean_reward": m[0] / max(m[4], 1), "crashed_episodes": m[1],
@@ -178,6 +243,8 @@ def main():
         }
         if valu is not None:
             line["roofline_secondary"] = valu
+        if args.rehearse_on_one_gpu:
+            line["rehearsal"] = "all %d ranks on cuda:0, gloo collectives: NOT a scaling measurement" % world
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(args, args.env_id, cfg, kw)
         print(json.dumps(line))

@@ -868,9 +868,10 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     s_cold[C_SSTEER][tid] = v.safe_steer; s_cold[C_SACC][tid] = v.safe_acc;
   }
   s_cold[C_TSPEED][tid] = v.tspeed;
-  if (kRoomy) { s_cold[C_CPSI][tid] = cpsi; s_cold[C_GVX][tid] = v.gvx; }
-  auto CPSI = [&]() -> double { return kRoomy ? s_cold[C_CPSI][tid] : cpsi; };
-  auto GVX = [&]() -> double { return kRoomy ? s_cold[C_GVX][tid] : v.gvx; };
+  // (form / slot selection is `if constexpr` throughout: an instantiation contains no code for slots it does not own)
+  if constexpr (kRoomy) { s_cold[C_CPSI][tid] = cpsi; s_cold[C_GVX][tid] = v.gvx; }
+  auto CPSI = [&]() -> double { if constexpr (kRoomy) return s_cold[C_CPSI][tid]; else return cpsi; };
+  auto GVX = [&]() -> double { if constexpr (kRoomy) return s_cold[C_GVX][tid]; else return v.gvx; };
   bool env_active = n_ctrl > 0;
   STAMP(0);  // load + setup
   for (int k = 0; k < c.nsub; k++) {
@@ -986,12 +987,15 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     memset(&cA, 0, sizeof cA);
     const bool shield_on = SHIELDED && live && !hdv && v.hist_len >= 2;  // gate safe_controller.py:232-239
     if (live) cA = predict<KIND, SHIELDED, MASS>(v, v.act_steer, dt, sv && !hdv);
-    auto park = [&](int base, const Cand &cc, double steer) {  // a candidate's LDS image
-      s_cold[base + 0][tid] = cc.x; s_cold[base + 1][tid] = cc.y; s_cold[base + 2][tid] = cc.h;
-      s_cold[base + 3][tid] = cc.gvx; s_cold[base + 4][tid] = cc.cpsi; s_cold[base + 5][tid] = steer;
-      s_cold[base + 6][tid] = (double)cc.pk;
+    auto park = [&](auto base_c, const Cand &cc, double steer) {  // a candidate's LDS image (shielded kernels only)
+      constexpr int base = decltype(base_c)::value;
+      if constexpr (SHIELDED) {
+        s_cold[base + 0][tid] = cc.x; s_cold[base + 1][tid] = cc.y; s_cold[base + 2][tid] = cc.h;
+        s_cold[base + 3][tid] = cc.gvx; s_cold[base + 4][tid] = cc.cpsi; s_cold[base + 5][tid] = steer;
+        s_cold[base + 6][tid] = (double)cc.pk;
+      }
     };
-    if (SHIELDED) park(C_A, cA, v.act_steer);
+    park(std::integral_constant<int, C_A>{}, cA, v.act_steer);
     STAMP(2);  // predict A
     // LC veto re-steers to the CURRENT lane (decentral_layer.py:501-506,739-744); identical to the
     // nominal command unless a lane change / lane hand-over is under way or the car crashed.
@@ -1001,35 +1005,42 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     const bool needB = SHIELDED && shield_on && (v.tlane != v.lane || v.crashed || sv);
     bool haveB = false;
     auto make_B = [&]() {
-      if (SHIELDED && needB && !haveB) {
-        double steerB = steering_control(v.x, v.y, v.h, v.v, v.lane);
-        if (sv) steerB = steer_vel_command(steerB, v.sang);
-        park(C_B, predict<KIND, true, MASS>(v, steerB, dt, sv), steerB);
-        haveB = true;
+      if constexpr (SHIELDED) {
+        if (needB && !haveB) {
+          double steerB = steering_control(v.x, v.y, v.h, v.v, v.lane);
+          if (sv) steerB = steer_vel_command(steerB, v.sang);
+          park(std::integral_constant<int, C_B>{}, predict<KIND, true, MASS>(v, steerB, dt, sv), steerB);
+          haveB = true;
+        }
       }
     };
     // the candidate a vehicle commits / shows to later vehicles: A, or B (from LDS) after a veto
     auto chosen = [&](bool useB) {
-      if (!SHIELDED) return cA;
-      const int base = useB ? C_B : C_A;  // both candidates sit in LDS; A's registers are free meanwhile
-      Cand cc;
-      cc.x = s_cold[base + 0][tid]; cc.y = s_cold[base + 1][tid]; cc.h = s_cold[base + 2][tid];
-      cc.gvx = s_cold[base + 3][tid]; cc.cpsi = s_cold[base + 4][tid];
-      const int pk = (int)s_cold[base + 6][tid];
-      cc.pk = pk; cc.lane = pk & 7;
-      return cc;
+      if constexpr (!SHIELDED) {
+        return cA;
+      } else {
+        const int base = useB ? C_B : C_A;  // both candidates sit in LDS; A's registers are free meanwhile
+        Cand cc;
+        cc.x = s_cold[base + 0][tid]; cc.y = s_cold[base + 1][tid]; cc.h = s_cold[base + 2][tid];
+        cc.gvx = s_cold[base + 3][tid]; cc.cpsi = s_cold[base + 4][tid];
+        const int pk = (int)s_cold[base + 6][tid];
+        cc.pk = pk; cc.lane = pk & 7;
+        return cc;
+      }
     };
     double new_acc = v.act_acc;
     bool use_B = false, veto = false;
     int new_flags = v.flags;
 
-    if (SHIELDED && __any(shield_on)) {
+    if constexpr (SHIELDED) {
+     if (__any(shield_on)) {
       // Which form runs is a compile-time property of the instantiation (kSerialOnly, above); debug_flags
       // bit0 forces the literal sweep in the kernels that carry both.
       bool serial = kSerialOnly || (c.debug_flags & 1) != 0;
       ShieldOut so;
       memset(&so, 0, sizeof so);
-      if (!serial) {
+      if constexpr (!kSerialOnly) {
+       if (!serial) {
         // ------------- parallel form of the front-to-back sweep --------------------------------
         // When vehicle i runs its shield, vehicle j is in its committed post-state if it steps
         // earlier (rank_j < rank_i), else in its pre-step state.  Post-states are the predicted
@@ -1066,7 +1077,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
             const int opk = dppx_i<m>(spk | (int)live << 8);
             const bool o_first = !i_first && p_rank < 99;  // partner steps before me (ranks are distinct)
             const Rel r = relate(v.x, v.y, pk_self, ((opk >> 8) & 1) != 0, ox, oy, oh, opk);
-            if (count5) s_cold[kColdB + m - 1][tid] = r.key;
+            if constexpr (count5) s_cold[kColdB + m - 1][tid] = r.key;
             // running "first in sorted order" per class: smaller key, ties by creation index (selects, no branches)
             // (the slot's flags ride in the index word -- bit 4: that partner steps before me, bit 5: its corner
             // flag -- instead of living as lane masks through the loop: 84 fewer SGPR spills)
@@ -1087,7 +1098,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           // count = 5 of close_vehicles_to: a slot exists only if its vehicle is among the 5 nearest
           // (with at most 6 vehicles per env every other vehicle is: the position count is skipped)
           nb.has_ol = j_ol >= 0; nb.has_oa = j_oa >= 0; nb.has_oar = j_oar >= 0;
-          if (count5) {
+          if constexpr (count5) {
             int pos_ol = 0, pos_oa = 0, pos_oar = 0;
 #pragma unroll
             for (int m = 1; m < G; m++) {
@@ -1125,7 +1136,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           irregular = irregular || (shield_on && nb.has_oar && oar_stepped);
           // ---- MASS: fixed point over the decided accelerations (HSS: one evaluation) ----------
           double acc_cur = shield_on ? 0.0 : v.act_acc;  // vehicles without a shield keep their command
-          if (kRoomy) v.gvx = GVX();
+          if constexpr (kRoomy) v.gvx = GVX();
           const ShieldStatic ss = shield_static<MASS>(c, v, cpsi_now, pk_self, nb);
           for (int round = 0; round <= st.N; round++) {
             if (MASS) {
@@ -1157,13 +1168,14 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         if (!serial && shield_on) {
           new_acc = so.acc; veto = so.veto; new_flags = so.flags; qt = so.qt;
         }
+       }
       }
       if (serial) {
         // ------------- literal front-to-back sweep (fallback / validation form) -----------------
         make_B();
         use_B = false; veto = false; new_acc = v.act_acc; new_flags = v.flags;
         // working copy of what the others see of me; committed stage by stage
-        if (kRoomy) { v.gvx = GVX(); cpsi = CPSI(); }
+        if constexpr (kRoomy) { v.gvx = GVX(); cpsi = CPSI(); }
         double wx = v.x, wy = v.y, wh = v.h, wg = hdv ? 1.0 : v.gvx, wacc = hdv ? kCbfAccLo : s_cold[C_SACC][tid], wvx = v.v * cpsi;
         double whx = s_cold[C_H2X][tid], whvx = s_cold[C_H2VX][tid];
         int wpk = pk_self;
@@ -1260,6 +1272,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         // the in-place history edits persist in the record that becomes state_hist[-2] (stepped HDV)
         if (MIXED && hdv && twin_shift != 0 && w_stepped) s_cold[C_H1X][tid] = whx;
       }
+     }
     }
     STAMP(6);  // serial fallback (if taken) + sweep exit
     if (SHIELDED && out.trace && live) {  // QP internals go out now so they need not stay in registers
@@ -1283,17 +1296,18 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         if (!hdv) {
           // a veto re-steers to the current lane; identical to the nominal command unless B was needed
           // (shielded kernels: the nominal command was parked with candidate A -- its register is free since then)
-          const double steer_nom = SHIELDED ? s_cold[C_A + 5][tid] : v.act_steer;
+          double steer_nom = v.act_steer;
+          if constexpr (SHIELDED) steer_nom = s_cold[C_A + 5][tid];
           s_cold[C_SSTEER][tid] = (SHIELDED && shield_on && veto && haveB) ? s_cold[C_B + 5][tid] : steer_nom;
           s_cold[C_SACC][tid] = acc; v.gvx = cc.gvx;
-          if (kRoomy) s_cold[C_GVX][tid] = cc.gvx;
+          if constexpr (kRoomy) s_cold[C_GVX][tid] = cc.gvx;
           if (sv) v.sang += s_cold[C_SSTEER][tid] * dt;  // steering_angle += safe steering velocity * dt (:139)
         }
         s_cold[C_H2X][tid] = s_cold[C_H1X][tid]; s_cold[C_H2VX][tid] = s_cold[C_H1VX][tid];  // log_step :187-201 (IDMVehicleHist: behavior.py:505-521)
         s_cold[C_H1X][tid] = v.x; s_cold[C_H1VX][tid] = v.v * cc.cpsi;
         if (v.hist_len < 2) v.hist_len++;
       }
-      if (kRoomy) s_cold[C_CPSI][tid] = cc.cpsi;
+      if constexpr (kRoomy) s_cold[C_CPSI][tid] = cc.cpsi;
       else if (SHIELDED || MIXED) cpsi = cc.cpsi;
       if (SHIELDED) pk_self = cc.pk;
     }
@@ -1340,7 +1354,8 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     if (out.trace && live) {
       double *t = out.trace + (long long)k * MM_T_COUNT * A + i;
       t[MM_T_X * A] = v.x; t[MM_T_Y * A] = v.y; t[MM_T_HEADING * A] = v.h; t[MM_T_SPEED * A] = v.v;
-      const double steer_tr = SHIELDED ? s_cold[C_A + 5][tid] : v.act_steer;
+      double steer_tr = v.act_steer;
+      if constexpr (SHIELDED) steer_tr = s_cold[C_A + 5][tid];
       t[MM_T_ACT_STEER * A] = steer_tr; t[MM_T_ACT_ACC * A] = v.act_acc;
       t[MM_T_SAFE_STEER * A] = (LC && !hdv) ? s_cold[C_SSTEER][tid] : steer_tr;
       t[MM_T_SAFE_ACC * A] = (LC && !hdv) ? s_cold[C_SACC][tid] : v.act_acc;

@@ -248,11 +248,15 @@ def reduce_rollout_metrics(metrics):
     RCCL on GPUs (backend "nccl"), gloo on CPU; 64 bytes, latency-bound.  In place; returns metrics."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # gloo (CPU tests, 1-GPU rehearsals) reduces host tensors; RCCL reduces in place on the device
+        via_host = metrics.is_cuda and dist.get_backend() == "gloo"
         sums, mn = metrics[:7].clone(), metrics[7:8].clone()
+        if via_host:
+            sums, mn = sums.cpu(), mn.cpu()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         dist.all_reduce(mn, op=dist.ReduceOp.MIN)
-        metrics[:7] = sums
-        metrics[7:8] = mn
+        metrics[:7] = sums.to(metrics.device)
+        metrics[7:8] = mn.to(metrics.device)
     return metrics
 
 
