@@ -5,9 +5,10 @@ agent a shared actor MLP forward, `np.random.choice` over the softmax, `env.step
 scaled by `reward_scale`, and a discounted return bootstrapped from the critic when the rollout
 ends mid-episode (`_discount_reward`, :364-370).  Here the same quantities are produced for E
 envs at once with every tensor staying in HBM: observations come straight out of `mm_step`, the
-actor runs as batched GEMMs (rocBLAS/hipBLASLt through torch -- plain library GEMMs, which is what
-they are), sampling is `torch.multinomial`, and the discounting is a reversed scan over the
-rollout with episode boundaries taken from `done`.
+actor forward + categorical sample is ONE launch (`mm_policy_act`: f32-input MFMA, inverse-CDF sampling exactly
+as `np.random.choice` does it, Philox uniforms; other actor modules run their own forward followed by
+`mm_sample_actions`), and the discounting is a reversed scan over the rollout with episode boundaries taken from
+`done`.
 
 The loop is launch-bound once `mm_step` takes < 0.5 ms (about a dozen small launches per policy
 step), so `use_graph=True` captures the WHOLE rollout -- T x (policy forward, sample, mm_step,
@@ -104,9 +105,11 @@ class DeviceRollout(object):
 
     def load_state_dict(self, d):
         self.env.load_state_dict(d["env"])
-        self.obs.copy_(d["obs"].to(self.obs.device))
+        self.obs.copy_(d["obs"].to(self.obs.device))  # in place: with a captured graph self.obs IS its static carry buffer
         self._sample_counter.copy_(d["sample_counter"].to(self._sample_counter.device))
-        self.sample_seed = int(d["sample_seed"])
+        if int(d["sample_seed"]) != self.sample_seed:
+            self.sample_seed = int(d["sample_seed"])
+            self._graph, self._static = None, None  # the seed is a kernel argument baked into the capture: re-capture
 
     @torch.no_grad()
     def act(self, obs):
@@ -150,14 +153,18 @@ class DeviceRollout(object):
             return self._interact()
         if self._graph is None:
             dev = self.obs.device
-            self._carry = self.obs  # static input/output of the graph: the observation carried between rollouts
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):  # warm-up outside capture (lazy library init, allocator)
-                self._interact()
-                self._carry.copy_(self.obs)
-                self.obs = self._carry
-            torch.cuda.current_stream(dev).wait_stream(side)
+            if not getattr(self, "_warmed", False):
+                # first capture only: one eager rollout outside capture (lazy library init, allocator warm-up).  It is a
+                # real rollout of the stream (state, RNG counter advance); its tensors are simply not returned.
+                self._carry = self.obs  # static input/output of the graph: the observation carried between rollouts
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    self._interact()
+                    self._carry.copy_(self.obs)
+                    self.obs = self._carry
+                torch.cuda.current_stream(dev).wait_stream(side)
+                self._warmed = True
             torch.cuda.synchronize(dev)
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
@@ -216,6 +223,11 @@ class DeviceRollout(object):
         env = self.env
         E, N, dev = env.E, env.N, self.obs.device
         was_auto = env.auto_reset
+        # The reference evaluates on a SEPARATE env (env_eval, run_mappo.py:146-171,300-306) and its training env keeps
+        # its own seed sequence and in-progress episode.  Here the batch is borrowed: snapshot everything an evaluation
+        # touches (state planes, episode counters, per-env RNG seeds, carried observation) and put it back afterwards,
+        # so the training stream continues exactly where it was instead of restarting from the test seeds.
+        saved_env, saved_obs = env.state_dict(), self.obs.clone()
         env.configure(auto_reset=False)
         try:
             # an evaluation episode is a function of its seed alone (the reference re-seeds the global RNG):
@@ -258,5 +270,6 @@ class DeviceRollout(object):
             return rewards[:tmax], (vspeed[:tmax], vpos[:tmax]), ext_info
         finally:
             env.configure(auto_reset=was_auto)
-            self.obs, _ = env.reset()
-            self.obs = self.obs.clone()
+            env.load_state_dict(saved_env)
+            # in place: after a graph capture self.obs is the graph's static carry buffer and must stay that tensor
+            self.obs.copy_(saved_obs)

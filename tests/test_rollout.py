@@ -269,3 +269,62 @@ def test_rollout_checkpoint_resume():
     out = b.interact()
     for k in ("states", "actions", "returns", "dones"):
         assert torch.equal(out[k], ref[k]), k
+
+
+def test_evaluate_leaves_the_training_stream_untouched():
+    """The reference evaluates on a separate env_eval (run_mappo.py:300-306): the training env keeps its seed sequence
+    and its in-progress episodes.  DeviceRollout.evaluate borrows the batch, so afterwards every plane, counter, per-env
+    RNG seed and the carried observation must be exactly what they were -- and the next rollout must be the one a
+    twin that never evaluated produces."""
+    def make():
+        torch.manual_seed(0)
+        env = oracle_env.OracleEnv(4, 4, env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
+                                   cbf_eta=0.03125, cbf_tau=0.5, seed=3, auto_reset=True)
+
+        class GreedyActor(ActorNetwork):  # deterministic actions: the comparison does not depend on the sampler's counter
+            def forward(self, state):
+                lp = super().forward(state)
+                return torch.where(lp == lp.max(-1, keepdim=True).values, 0.0, -float("inf")).to(lp.dtype)
+        return DeviceRollout(env, GreedyActor(30, 128, 5), CriticNetwork(30, 5, 128), roll_out_n_steps=15)
+    a, b = make(), make()
+    a.interact(); b.interact()
+    before = a.env.state.clone()
+    a.evaluate(seeds=[7, 8, 9, 10])
+    assert torch.equal(a.env.state, before), "state planes / counters / seeds changed by evaluate()"
+    assert torch.equal(a.env.seeds, b.env.seeds) and torch.equal(a.env.env_i32, b.env.env_i32)
+    assert torch.equal(a.obs, b.obs)
+    ra, rb = a.interact(), b.interact()
+    for k in ("states", "actions", "returns", "dones"):
+        assert torch.equal(ra[k], rb[k]), k
+    a.evaluate(seeds=[7, 8, 9, 10])  # and a second evaluation does not replay the first post-evaluation spawn either
+    ra, rb = a.interact(), b.interact()
+    assert torch.equal(ra["states"], rb["states"])
+
+
+@pytest.mark.gpu
+def test_graph_rollout_survives_evaluate_and_reseed():
+    """hipGraph replay interleaved with evaluate() and a load_state_dict that changes the sampler seed: the static carry
+    buffer is refreshed in place and the graph is re-captured when a baked-in argument changed (eager twin == graph)."""
+    from marl_mass_amd import VecMergeEnv
+    E, N, T = 2048, 8, 12
+    kw = dict(config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5, seed=9, auto_reset=True)
+    torch.manual_seed(3)
+    actor, critic = ActorNetwork(30, 128, 5).cuda(), CriticNetwork(30, 5, 128).cuda()
+    eager = DeviceRollout(VecMergeEnv(E, N, **kw), actor, critic, roll_out_n_steps=T, sample_seed=4)
+    graph = DeviceRollout(VecMergeEnv(E, N, **kw), actor, critic, roll_out_n_steps=T, sample_seed=4, use_graph=True)
+    graph.interact()                    # warm-up + capture + first replay = 2 rollouts
+    eager.interact(); eager.interact()
+    seeds = list(range(100, 100 + E))
+    re_, rg = eager.evaluate(seeds=seeds), graph.evaluate(seeds=seeds)
+    assert torch.equal(re_[0].nan_to_num(), rg[0].nan_to_num())
+    a, b = eager.interact(), graph.interact()
+    torch.cuda.synchronize()
+    for k in ("states", "actions", "returns", "dones"):
+        assert torch.equal(a[k], b[k]), ("after evaluate", k)
+    ck = eager.state_dict()
+    ck["sample_seed"] = 77              # a new sampler seed must reach the captured kernels too
+    eager.load_state_dict(ck); graph.load_state_dict(ck)
+    a, b = eager.interact(), graph.interact()
+    torch.cuda.synchronize()
+    for k in ("states", "actions", "returns", "dones"):
+        assert torch.equal(a[k], b[k]), ("after reseed", k)
