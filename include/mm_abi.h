@@ -148,6 +148,15 @@ typedef struct MMConfig {
                                                 stops at (Mehrotra predictor-corrector, NT scaling, abstol 1e-7 /
                                                 reltol 1e-6 / feastol 1e-7, <= 100 iterations), incl. its "unknown"
                                                 status -> is_optimal = 0 (include/mm_qp.h) */
+  int32_t traffic_density;      /* device reset / auto-reset vehicle counts (MergeEnv._num_vehicles, merge_env_v1.py:180-211):
+                                   0  fixed: N - n_hdv CAVs + n_hdv HDVs in every episode (BASELINE configs);
+                                   1..3  config["traffic_density"]: every episode draws num_CAV and num_HDV uniformly from
+                                         {1,2,3} / {2,3,4} / CAV {4,5,6}, HDV {3,4,5} (ragged batch: unused slots are
+                                         absent, MM_B_KIND = 0); N is the slot capacity and must hold the largest draw */
+  int32_t mixed_traffic;        /* with traffic_density > 0: 1 = the drawn HDVs are IDM/MOBIL vehicles, 0 = they become CAVs
+                                   (config["mixed_traffic"] False / traffic_type "cav": num_CAV += num_HDV, :206-209) */
+  int32_t num_cav;              /* with traffic_density > 0: reset(num_CAV=...) override of the CAV draw, 0 = draw (:185,192,199) */
+  int32_t reserved1;
 } MMConfig;
 #define MM_QP_EXACT 0
 #define MM_QP_IPM 1

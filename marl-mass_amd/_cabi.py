@@ -54,7 +54,8 @@ class MMConfig(C.Structure):
                 ("merging_lane_cost", C.c_double), ("reward_speed_lo", C.c_double),
                 ("reward_speed_hi", C.c_double), ("cbf_eta", C.c_double), ("cbf_tau", C.c_double),
                 ("seed", C.c_uint64), ("n_hdv", C.c_int32), ("agent_reward", C.c_int32),
-                ("lateral_control", C.c_int32), ("qp_solver", C.c_int32)]
+                ("lateral_control", C.c_int32), ("qp_solver", C.c_int32),
+                ("traffic_density", C.c_int32), ("mixed_traffic", C.c_int32), ("num_cav", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class MMStepOut(C.Structure):
@@ -119,7 +120,7 @@ def qp_solver_id(name):
 
 
 def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0, debug_flags=0,
-                n_hdv=0, qp_solver="exact"):
+                n_hdv=0, qp_solver="exact", draw_counts=False, num_cav=0):
     """env.config dict (+ CBFType.GAMMA_B / CBFType.TAU, run_mappo.py:138-139) -> MMConfig."""
     c = MMConfig()
     c.abi_version = MM_ABI_VERSION
@@ -150,6 +151,20 @@ def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs
     ar = config.get("agent_reward", "default") if c.env_kind == ENV_V1 else "default"
     c.agent_reward = {"srew": 1, "mrew": 2}.get(ar, 0)  # anything else falls back to the default reward (:446)
     c.qp_solver = qp_solver_id(qp_solver)
+    # draw_counts: the device reset draws the vehicle counts per episode like MergeEnv._num_vehicles does
+    # (config["traffic_density"] 1..3, config["mixed_traffic"]); otherwise every episode has N - n_hdv CAVs + n_hdv HDVs
+    c.traffic_density = int(config.get("traffic_density", 1)) if draw_counts else 0
+    if draw_counts and c.traffic_density not in (1, 2, 3):
+        raise ValueError("traffic_density must be 1, 2 or 3 when the vehicle counts are drawn")
+    mixed = config.get("mixed_traffic", True)
+    if c.env_kind == ENV_V1:  # MergeEnvLCMARL._num_vehicles: traffic_type decides (merge_env_v1.py:476-495)
+        tt = config.get("traffic_type", "cav")
+        if tt in ("mixed", "cav"):
+            mixed = tt == "mixed"
+        elif draw_counts:
+            raise NotImplementedError("traffic_type=%r is not supported by the device-side count draw" % (tt,))
+    c.mixed_traffic = int(bool(mixed))
+    c.num_cav = int(num_cav)
     return c
 
 

@@ -37,6 +37,7 @@ struct DevCfg {
   int agent_reward;
   int steer_vel;  // lateral_control == "steer_vel" (v1 CAVs; handled by the MIXED = general instantiations)
   int *err;       // device error latch of the handle (MM_LATCH_* bits), read by mm_poll_errors
+  int traffic_density, mixed_traffic, num_cav;  // per-episode vehicle-count draw (MergeEnv._num_vehicles); 0 = fixed counts
 };
 // conditions the reference raises from inside step(); a launch can only latch them (include/mm_abi.h: mm_poll_errors)
 #define MM_LATCH_QP_BOUNDS 1  // CBFType.check_bounds, cbf.py:87-96
@@ -324,6 +325,19 @@ MM_DEV void init_vehicle(Veh &v) {  // kinematics.py:36-53, controller.py:35-50,
   v.h1x = v.h1vx = v.h2x = v.h2vx = 0;
   v.sang = 0;  // safe_controller.py:54
   v.crashed = 0; v.hl = MM_HL_NONE; v.flags = 0; v.hist_len = 0;
+}
+// MergeEnv._num_vehicles (merge_env_v1.py:180-211, :476-495): block 64 of the episode's stream, word 0 -> num_CAV,
+// word 1 -> num_HDV, uniform over 3 values each; traffic_density 0 keeps the given (fixed) counts
+MM_DEV void episode_counts(const DevCfg &c, uint64_t seed, uint32_t episode, int &n_cav, int &n_hdv) {
+  if (c.traffic_density <= 0) return;
+  uint32_t w[4];
+  rng_block(seed, episode, 64u, w);
+  const int lo_c = c.traffic_density == 1 ? 1 : (c.traffic_density == 2 ? 2 : 4);
+  const int lo_h = c.traffic_density == 1 ? 1 : (c.traffic_density == 2 ? 2 : 3);
+  int nc = c.num_cav > 0 ? c.num_cav : lo_c + (int)(((uint64_t)w[0] * 3u) >> 32);
+  int nh = lo_h + (int)(((uint64_t)w[1] * 3u) >> 32);
+  if (!c.mixed_traffic) { nc = nc + nh; nh = 0; }  // :206-209
+  n_cav = nc; n_hdv = nh;
 }
 MM_DEV int spawn_vehicle(Veh &v, int a, int n_cav, int n_hdv, uint64_t seed, uint32_t episode) {
   uint32_t r[12], blk[4];
@@ -1517,8 +1531,15 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     Veh nv;
     memset(&nv, 0, sizeof nv);
     int nm = 0;
-    if (valid && v.present) nm = spawn_vehicle(nv, a, n_ctrl, n_veh - n_ctrl, seed, (uint32_t)episode);
-    if (valid && v.present) {
+    int nc = n_ctrl, nh = n_veh - n_ctrl;  // fixed counts: the env keeps its own composition
+    episode_counts(c, seed, (uint32_t)episode, nc, nh);
+    const bool spawn = valid && (c.traffic_density > 0 ? a < nc + nh : v.present);
+    if (spawn) nm = spawn_vehicle(nv, a, nc, nh, seed, (uint32_t)episode);
+    if (c.traffic_density > 0 && valid) {  // ragged batch: the slot's occupancy changes with the episode
+      if (!spawn) { v.present = false; v.kind = 0; }
+      st.B[MM_B_KIND * A + i] = spawn ? (uint8_t)nv.kind : (uint8_t)0;
+    }
+    if (spawn) {
       v = nv;
       s_cold[C_H1X][tid] = v.h1x; s_cold[C_H1VX][tid] = v.h1vx; s_cold[C_H2X][tid] = v.h2x; s_cold[C_H2VX][tid] = v.h2vx;
       s_cold[C_SSTEER][tid] = v.safe_steer; s_cold[C_SACC][tid] = v.safe_acc; s_cold[C_TSPEED][tid] = v.tspeed;
@@ -1565,8 +1586,11 @@ __global__ __launch_bounds__(256) void reset_kernel(DevCfg c, DevState st, int m
       if (seeds_in && a == 0) st.seeds[e] = seeds_in[e];
       const uint64_t seed = seeds_in ? seeds_in[e] : st.seeds[e];
       int nm = 0;
+      int nc = st.N - c.n_hdv, nh = c.n_hdv;
+      episode_counts(c, seed, (uint32_t)episode, nc, nh);
       if (valid) {
-        nm = spawn_vehicle(v, a, st.N - c.n_hdv, c.n_hdv, seed, (uint32_t)episode);
+        if (a < nc + nh) nm = spawn_vehicle(v, a, nc, nh, seed, (uint32_t)episode);
+        else { memset(&v, 0, sizeof v); v.hl = MM_HL_NONE; }  // unused slot of a ragged batch
         st.B[MM_B_KIND * st.A + i] = (uint8_t)v.kind;
       }
       n_merge = shfl_i(nm, gb);
@@ -1866,6 +1890,7 @@ static DevCfg dev_cfg(const MMHandle h) {
   d.agent_reward = c.env_kind == MM_ENV_V1 ? c.agent_reward : 0;
   d.steer_vel = (c.env_kind == MM_ENV_V1 && c.lateral_control == MM_LATERAL_STEER_VEL) ? 1 : 0;
   d.err = h->dev_err;
+  d.traffic_density = c.traffic_density; d.mixed_traffic = c.mixed_traffic; d.num_cav = c.num_cav;
   return d;
 }
 static DevState dev_state(const MMHandle h) {
@@ -1914,8 +1939,13 @@ extern "C" int32_t mm_reset(MMHandle h, const uint8_t *env_mask, const uint64_t 
   if (!h) return MM_ERR_INVALID_ARG;
   {  // each road has 6 spawn slots shared by its CAVs and HDVs (merge_env_v1.py:284-285; np.random.choice raises beyond)
     const int n_hdv = h->cfg.n_hdv, n_cav = h->N - n_hdv, ramp = (n_cav - n_cav / 2) + (n_hdv - n_hdv / 2);
-    if (ramp > 6) {
+    if (h->cfg.traffic_density == 0 && ramp > 6) {
       snprintf(h->err, sizeof h->err, "%d CAVs + %d HDVs need %d ramp spawn slots, the road has 6", n_cav, n_hdv, ramp);
+      return MM_ERR_INVALID_ARG;
+    }
+    const int td = h->cfg.traffic_density, need = td == 0 ? 0 : (td == 1 ? 6 : (td == 2 ? 8 : 11));  // largest draw
+    if (td < 0 || td > 3 || h->N < need) {
+      snprintf(h->err, sizeof h->err, "traffic_density %d draws up to %d vehicles per episode, the batch has %d slots", td, need, h->N);
       return MM_ERR_INVALID_ARG;
     }
   }
@@ -1995,7 +2025,8 @@ static void launch_step_g(MMHandle h, const int32_t *actions, const MMStepOut *o
 #else
     launch_step_ipm_g<G>(h, actions, out, s);
 #endif
-  else if (h->cfg.n_hdv > 0 || (h->cfg.env_kind == MM_ENV_V1 && h->cfg.lateral_control == MM_LATERAL_STEER_VEL))
+  else if (h->cfg.n_hdv > 0 || (h->cfg.traffic_density > 0 && h->cfg.mixed_traffic) ||
+           (h->cfg.env_kind == MM_ENV_V1 && h->cfg.lateral_control == MM_LATERAL_STEER_VEL))
 #if MM_TU == 1
     mm_launch_step_general(h, actions, out, s);
 #else

@@ -31,7 +31,7 @@ class BatchedMergeEnv(object):
 
     def __init__(self, clib, E, N, env_id="merge-multi-agent-v1", config=None, device="cpu",
                  cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0, first_env=0,
-                 trace=False, debug_flags=0, n_hdv=0, qp_solver="exact"):
+                 trace=False, debug_flags=0, n_hdv=0, qp_solver="exact", draw_counts=False, num_cav=0):
         self.clib, self.E, self.N = clib, int(E), int(N)
         self.env_id = env_id
         self.device = torch.device(device)
@@ -43,6 +43,9 @@ class BatchedMergeEnv(object):
         self.debug_flags = debug_flags
         self.qp_solver = qp_solver  # "exact" (closed-form KKT point) | "ipm" (cvxopt's coneqp iterate, fidelity mode)
         self.n_hdv = int(n_hdv)  # device reset: the last n_hdv vehicles of every env are IDM/MOBIL HDVs
+        # draw_counts: every (re)spawn draws its vehicle counts as MergeEnv._num_vehicles does (config["traffic_density"]
+        # 1..3, config["mixed_traffic"] / "traffic_type"); N is then the slot capacity of a ragged batch
+        self.draw_counts, self.num_cav = bool(draw_counts), int(num_cav)
         self.n_f = 6 if env_id == "merge-multi-agent-v1" else 5
         self.n_s = 5 * self.n_f  # merge_env_v1.py:28 / :413
         self._cfg = self._make_cfg()
@@ -90,13 +93,14 @@ class BatchedMergeEnv(object):
     def _make_cfg(self):
         return abi.make_config(self.env_id, self.config, cbf_eta=self.cbf_eta, cbf_tau=self.cbf_tau,
                                auto_reset=self.auto_reset, obs_f64=self.obs_f64, seed=self.seed,
-                               debug_flags=self.debug_flags, n_hdv=self.n_hdv, qp_solver=self.qp_solver)
+                               debug_flags=self.debug_flags, n_hdv=self.n_hdv, qp_solver=self.qp_solver,
+                               draw_counts=self.draw_counts, num_cav=self.num_cav)
 
     def configure(self, config=None, **kw):
         """env.config[k] = v after construction (run_mappo.py:145-171); CBFType globals via kw."""
         if config:
             self.config.update(config)
-        for k in ("cbf_eta", "cbf_tau", "auto_reset", "seed", "n_hdv", "qp_solver"):
+        for k in ("cbf_eta", "cbf_tau", "auto_reset", "seed", "n_hdv", "qp_solver", "draw_counts", "num_cav"):
             if k in kw:
                 setattr(self, k, kw[k])
         self._cfg = self._make_cfg()

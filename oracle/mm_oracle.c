@@ -1233,6 +1233,20 @@ static void init_vehicle(Veh *v) {
   v->local_reward = v->regional_reward = 0;
 }
 
+/* MergeEnv._num_vehicles (merge_env_v1.py:180-211; MergeEnvLCMARL :476-495 sets mixed_traffic from traffic_type) with the
+ * device RNG: block 64 of the episode's stream, word 0 -> num_CAV, word 1 -> num_HDV, each uniform over its 3 values
+ * (np.random.choice(np.arange(lo, lo + 3), 1)).  traffic_density 0 = the fixed counts of the BASELINE configs. */
+static void episode_counts(const MMConfig *cfg, int N, uint64_t seed, uint32_t episode, int *n_cav, int *n_hdv) {
+  *n_cav = N - cfg->n_hdv; *n_hdv = cfg->n_hdv;
+  if (cfg->traffic_density <= 0) return;
+  const int lo_c = cfg->traffic_density == 1 ? 1 : (cfg->traffic_density == 2 ? 2 : 4);
+  const int lo_h = cfg->traffic_density == 1 ? 1 : (cfg->traffic_density == 2 ? 2 : 3);
+  int nc = cfg->num_cav > 0 ? cfg->num_cav : lo_c + (int)(((uint64_t)rng_u32(seed, episode, 4u * 64u) * 3u) >> 32);
+  int nh = lo_h + (int)(((uint64_t)rng_u32(seed, episode, 4u * 64u + 1u) * 3u) >> 32);
+  if (!cfg->mixed_traffic) { nc = nc + nh; nh = 0; } /* :206-209 */
+  *n_cav = nc; *n_hdv = nh;
+}
+
 /* merge_env_v1.py:265-364 _make_vehicles for N CAVs / 0 HDVs with the device RNG stream
  * (draw plan documented in DESIGN.md "Device reset"): N/2 on ab0 first, the rest on jk0. */
 static void spawn_env(Env *e, int n_cav, int n_hdv, uint64_t seed, uint32_t episode) {
@@ -1406,8 +1420,13 @@ int32_t mm_reset(MMHandle h, const uint8_t *env_mask, const uint64_t *seeds_in, 
   if (!h) return MM_ERR_INVALID_ARG;
   { /* each road has 6 spawn slots shared by its CAVs and HDVs (merge_env_v1.py:284-285; np.random.choice raises beyond) */
     const int n_hdv = h->cfg.n_hdv, n_cav = h->N - n_hdv, ramp = (n_cav - n_cav / 2) + (n_hdv - n_hdv / 2);
-    if (ramp > 6) {
+    if (h->cfg.traffic_density == 0 && ramp > 6) {
       snprintf(h->err, sizeof h->err, "%d CAVs + %d HDVs need %d ramp spawn slots, the road has 6", n_cav, n_hdv, ramp);
+      return MM_ERR_INVALID_ARG;
+    }
+    const int td = h->cfg.traffic_density, need = td == 0 ? 0 : (td == 1 ? 6 : (td == 2 ? 8 : 11)); /* largest draw */
+    if (td < 0 || td > 3 || h->N < need) {
+      snprintf(h->err, sizeof h->err, "traffic_density %d draws up to %d vehicles per episode, the batch has %d slots", td, need, h->N);
       return MM_ERR_INVALID_ARG;
     }
   }
@@ -1419,7 +1438,9 @@ int32_t mm_reset(MMHandle h, const uint8_t *env_mask, const uint64_t *seeds_in, 
     load_env(h, e_idx, &e);
     if (seeds_in) seeds[e_idx] = seeds_in[e_idx];
     int episode = e.episode;
-    spawn_env(&e, h->N - h->cfg.n_hdv, h->cfg.n_hdv, seeds[e_idx], (uint32_t)episode);
+    int n_cav, n_hdv;
+    episode_counts(&h->cfg, h->N, seeds[e_idx], (uint32_t)episode, &n_cav, &n_hdv);
+    spawn_env(&e, n_cav, n_hdv, seeds[e_idx], (uint32_t)episode);
     e.episode = episode + 1;
     store_env(h, e_idx, &e);
     write_obs(h, &e, e_idx, obs, avail);
@@ -1537,7 +1558,9 @@ int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *out, MMStre
     if (mh < m_min) m_min = mh;
     if (done && cfg->auto_reset) { /* caller-side `if done: env.reset()` (marl/mappo.py:133-135) */
       int episode = e.episode;
-      spawn_env(&e, e.n_ctrl, e.n - e.n_ctrl, seeds[e_idx], (uint32_t)episode);
+      int n_cav = e.n_ctrl, n_hdv = e.n - e.n_ctrl; /* fixed counts: the episode keeps the env's own composition */
+      if (cfg->traffic_density > 0) episode_counts(cfg, h->N, seeds[e_idx], (uint32_t)episode, &n_cav, &n_hdv);
+      spawn_env(&e, n_cav, n_hdv, seeds[e_idx], (uint32_t)episode);
       e.episode = episode + 1;
     }
     store_env(h, e_idx, &e);

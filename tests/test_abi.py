@@ -48,7 +48,7 @@ def test_library_exports_abi(lib):
 
 
 def test_struct_sizes():
-    assert ctypes.sizeof(abi.MMConfig) == 10 * 4 + 9 * 8 + 8 + 4 * 4
+    assert ctypes.sizeof(abi.MMConfig) == 10 * 4 + 9 * 8 + 8 + 8 * 4
     assert ctypes.sizeof(abi.MMStepOut) == 14 * 8
 
 
