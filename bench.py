@@ -135,7 +135,10 @@ def main():
     kw = dict(cbf_eta=0.03125 if args.shield != "none" else 0.0, cbf_tau=cfg["HEADWAY_TIME"], seed=1000,
               auto_reset=True, obs_f64=args.obs_f64, n_hdv=args.hdv, qp_solver=args.qp_solver)
     env = VecMergeEnv(E, N, env_id=args.env_id, config=cfg, device=dev, first_env=first_env, **kw)
-    metrics = env.enable_metrics()
+    if os.environ.get("MM_BENCH_NO_METRICS"):  # tuning experiment: no in-kernel metric accumulation
+        metrics = torch.zeros(8, dtype=torch.float64, device=dev)
+    else:
+        metrics = env.enable_metrics()
     env.reset()
     g = torch.Generator(device=dev).manual_seed(123 + rank)
     p = torch.tensor([0.1, 0.6, 0.1, 0.1, 0.1], device=dev)

@@ -23,6 +23,21 @@
 #define MMM_FN static inline
 #endif
 
+/* One Horner step p*z + C with a compile-time coefficient C.  On gfx950 it is spelled as the VOP3 instruction with the
+ * coefficient in a scalar register pair: left to itself the compiler (ROCm 7.2, under the register pressure of the fused
+ * step kernel) parks all ~70 Taylor coefficients in VGPRs for the whole kernel and emits `v_mov_b64 tmp, C; v_fmac_f64
+ * tmp, p, z` per step -- two vector instructions and ~30 resident VGPRs for what is one fused multiply-add.  With "s" the
+ * coefficient is two rematerialisable s_mov_b32 on the scalar unit.  Same IEEE operation, same bits as fma(). */
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__gfx950__)
+MMM_FN double mmm_fma_c(double p, double z, double c) {
+  double r;
+  __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(c));
+  return r;
+}
+#else
+#define mmm_fma_c(p, z, c) fma((p), (z), (c))
+#endif
+
 #define MMM_PIO2_1 0x1.921fb54400000p+0 /* 1.5707963267341256 */
 #define MMM_PIO2_1T 0x1.0b4611a626331p-34 /* 6.0771005065061922e-11 */
 #define MMM_PIO2_HI 0x1.921fb54442d18p+0 /* 1.5707963267948966 */
@@ -93,15 +108,15 @@
 MMM_FN double mmm_ksin(double r) {
   double z = r * r;
   double p = MMM_S7;
-  p = fma(p, z, MMM_S6); p = fma(p, z, MMM_S5); p = fma(p, z, MMM_S4);
-  p = fma(p, z, MMM_S3); p = fma(p, z, MMM_S2); p = fma(p, z, MMM_S1);
+  p = mmm_fma_c(p, z, MMM_S6); p = mmm_fma_c(p, z, MMM_S5); p = mmm_fma_c(p, z, MMM_S4);
+  p = mmm_fma_c(p, z, MMM_S3); p = mmm_fma_c(p, z, MMM_S2); p = mmm_fma_c(p, z, MMM_S1);
   return fma(r * z, p, r);
 }
 MMM_FN double mmm_kcos(double r) {
   double z = r * r;
   double q = MMM_C8;
-  q = fma(q, z, MMM_C7); q = fma(q, z, MMM_C6); q = fma(q, z, MMM_C5);
-  q = fma(q, z, MMM_C4); q = fma(q, z, MMM_C3); q = fma(q, z, MMM_C2);
+  q = mmm_fma_c(q, z, MMM_C7); q = mmm_fma_c(q, z, MMM_C6); q = mmm_fma_c(q, z, MMM_C5);
+  q = mmm_fma_c(q, z, MMM_C4); q = mmm_fma_c(q, z, MMM_C3); q = mmm_fma_c(q, z, MMM_C2);
   return fma(z * z, q, fma(-0.5, z, 1.0));
 }
 /* Cody-Waite reduction by pi/2 (two-part constant: exact for |k| < 2^19) */
@@ -145,9 +160,9 @@ MMM_FN double mmm_atan01(double ax, double *lo_out) {
   double t = (ax - c) / fma(ax, c, 1.0); /* j == 0: (ax - 0) / 1 == ax exactly, no special case needed */
   double z = t * t;
   double p = MMM_A10;
-  p = fma(p, z, MMM_A9); p = fma(p, z, MMM_A8); p = fma(p, z, MMM_A7); p = fma(p, z, MMM_A6);
-  p = fma(p, z, MMM_A5); p = fma(p, z, MMM_A4); p = fma(p, z, MMM_A3); p = fma(p, z, MMM_A2);
-  p = fma(p, z, MMM_A1);
+  p = mmm_fma_c(p, z, MMM_A9); p = mmm_fma_c(p, z, MMM_A8); p = mmm_fma_c(p, z, MMM_A7); p = mmm_fma_c(p, z, MMM_A6);
+  p = mmm_fma_c(p, z, MMM_A5); p = mmm_fma_c(p, z, MMM_A4); p = mmm_fma_c(p, z, MMM_A3); p = mmm_fma_c(p, z, MMM_A2);
+  p = mmm_fma_c(p, z, MMM_A1);
   double pt = fma(t * z, p, t);
   double hi = j == 0 ? 0.0 : (j == 1 ? MMM_ATAN_HI_1 : (j == 2 ? MMM_ATAN_HI_2 : (j == 3 ? MMM_ATAN_HI_3 : MMM_ATAN_HI_4)));
   double lo = j == 0 ? 0.0 : (j == 1 ? MMM_ATAN_LO_1 : (j == 2 ? MMM_ATAN_LO_2 : (j == 3 ? MMM_ATAN_LO_3 : MMM_ATAN_LO_4)));
@@ -178,9 +193,9 @@ MMM_FN double mmm_exp(double x) {
   double r = fma(-k, MMM_LN2_HI, x);
   r = fma(-k, MMM_LN2_LO, r);
   double p = MMM_E14;
-  p = fma(p, r, MMM_E13); p = fma(p, r, MMM_E12); p = fma(p, r, MMM_E11); p = fma(p, r, MMM_E10);
-  p = fma(p, r, MMM_E9); p = fma(p, r, MMM_E8); p = fma(p, r, MMM_E7); p = fma(p, r, MMM_E6);
-  p = fma(p, r, MMM_E5); p = fma(p, r, MMM_E4); p = fma(p, r, MMM_E3); p = fma(p, r, MMM_E2);
+  p = mmm_fma_c(p, r, MMM_E13); p = mmm_fma_c(p, r, MMM_E12); p = mmm_fma_c(p, r, MMM_E11); p = mmm_fma_c(p, r, MMM_E10);
+  p = mmm_fma_c(p, r, MMM_E9); p = mmm_fma_c(p, r, MMM_E8); p = mmm_fma_c(p, r, MMM_E7); p = mmm_fma_c(p, r, MMM_E6);
+  p = mmm_fma_c(p, r, MMM_E5); p = mmm_fma_c(p, r, MMM_E4); p = mmm_fma_c(p, r, MMM_E3); p = mmm_fma_c(p, r, MMM_E2);
   p = fma(p, r * r, r) + 1.0; /* 1 + r + r^2 (1/2 + ...) */
   return ldexp(p, (int)k);
 }
@@ -193,9 +208,9 @@ MMM_FN double mmm_log(double x) {
   double s = f / (2.0 + f);
   double z = s * s;
   double p = MMM_L11;
-  p = fma(p, z, MMM_L10); p = fma(p, z, MMM_L9); p = fma(p, z, MMM_L8); p = fma(p, z, MMM_L7);
-  p = fma(p, z, MMM_L6); p = fma(p, z, MMM_L5); p = fma(p, z, MMM_L4); p = fma(p, z, MMM_L3);
-  p = fma(p, z, MMM_L2); p = fma(p, z, MMM_L1);
+  p = mmm_fma_c(p, z, MMM_L10); p = mmm_fma_c(p, z, MMM_L9); p = mmm_fma_c(p, z, MMM_L8); p = mmm_fma_c(p, z, MMM_L7);
+  p = mmm_fma_c(p, z, MMM_L6); p = mmm_fma_c(p, z, MMM_L5); p = mmm_fma_c(p, z, MMM_L4); p = mmm_fma_c(p, z, MMM_L3);
+  p = mmm_fma_c(p, z, MMM_L2); p = mmm_fma_c(p, z, MMM_L1);
   double l = 2.0 * fma(s * z, p, s);
   double de = (double)e;
   return fma(de, MMM_LN2_HI, l + de * MMM_LN2_LO);

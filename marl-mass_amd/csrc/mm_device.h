@@ -191,6 +191,17 @@ MM_DEV bool has_corner_inside(double c1x, double c1y, double l1, double w1, doub
   }
   return any;
 }
+// Exact early-out for rects_intersect.  The 9-point test can only succeed if a point of box A lies inside box B (B as the
+// upstream code rotates it, i.e. by +heading or -heading: the bound below is symmetric in the sign).  Along a WORLD axis
+// a box with half-extents (l, w) and heading h reaches at most l + w|h| in x and w + l|h| in y (cos h <= 1, |sin h| <= |h|
+// for every h), so if the centres are further apart than the two reaches on either axis the boxes are disjoint and every
+// point test is false.  The 1e-6 margin dwarfs the rounding of the test itself (~1e-13): never a different answer.
+MM_DEV bool boxes_may_touch(double dx, double dy, double ha, double hb, double lb, double wb) {
+  const double aa = fabs(ha), ab = fabs(hb);
+  const double la = 0.9 * kVehLength / 2, wa = 0.9 * kVehWidth / 2;
+  const double rx = (la + wa * aa) + (lb + wb * ab) + 1e-6, ry = (wa + la * aa) + (wb + lb * ab) + 1e-6;
+  return !(fabs(dx) > rx) && !(fabs(dy) > ry);
+}
 // kinematics.py:202-209 _is_colliding (caller did the 5 m pre-check)
 MM_DEV bool rects_intersect(double ax, double ay, double ah, double ox, double oy, double ol,
                             double ow, double oh) {

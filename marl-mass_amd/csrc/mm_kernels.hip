@@ -65,11 +65,13 @@ struct DevState {
 // Diagnostic build only (-DMM_STAMPS): per-phase cycle sums (s_memtime) accumulated by lane 0 of each
 // wave into a __device__ array the host reads with mm_debug_read_stamps.  Never in the product build.
 #ifdef MM_STAMPS
-__device__ unsigned long long g_stamps[16];
+// lane k of every wave accumulates phase k in a register; one plain store per wave at the end (no atomics in flight)
+#define MM_STAMP_WAVES (1 << 16)
+__device__ unsigned long long g_stamps_w[MM_STAMP_WAVES * 16];
 #define STAMP(k)                                                                         \
   do {                                                                                   \
     unsigned long long _t = __builtin_amdgcn_s_memtime();                                \
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_stamps[k], _t - _t_last);                  \
+    if ((threadIdx.x & 63) == (k)) _t_acc += _t - _t_last;                               \
     _t_last = __builtin_amdgcn_s_memtime();                                              \
   } while (0)
 #else
@@ -801,7 +803,7 @@ constexpr int step_min_waves() { return SHIELD == MM_SHIELD_NONE ? (MIXED ? MM_G
 // general (MIXED) instantiations only, which run the literal sweep -- one QP per vehicle per sub-step, as the reference
 template <int G, int KIND, int SHIELD, bool MIXED, bool IPM = false>
 #ifndef MM_STEP_BLOCK
-#define MM_STEP_BLOCK 256
+#define MM_STEP_BLOCK 64  // one wave per workgroup: waves of a 256-thread block drifted ~12 % apart and the block held its LDS until the slowest was done (0.355 -> 0.333 ms)
 #endif
 __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
                                                    MMStepOut out, double *metrics) {
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   const double dt = c.dt;
 
 #ifdef MM_STAMPS
-  unsigned long long _t_last = __builtin_amdgcn_s_memtime();
+  unsigned long long _t_last = __builtin_amdgcn_s_memtime(), _t_acc = 0;
 #endif
   Veh v;
   const bool sv = MIXED && KIND == MM_ENV_V1 && c.steer_vel != 0;
@@ -1176,8 +1178,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         }
         serial = __any(irregular);
 #ifdef MM_STAMPS
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&g_stamps[13], 1ull); if (serial) atomicAdd(&g_stamps[14], 1ull); }
-        if (irregular) atomicAdd(&g_stamps[15], 1ull);
+        if ((threadIdx.x & 63) == 13) _t_acc += 1;
 #endif
         if (!serial && shield_on) {
           new_acc = so.acc; veto = so.veto; new_flags = so.flags; qt = so.qt;
@@ -1328,19 +1329,40 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
 
     STAMP(7);  // commit
     // ---------------- collisions (road.py:288-292, kinematics.py:175-209) ----------------------
-    unsigned hits = 0;
+    // Which pairs need the 9-point rotated-rectangle test at all?  The reference's own pre-check (norm <= LENGTH) lets
+    // through every pair of vehicles side by side on bc0 / bc1 and every vehicle passing the obstacle; boxes_may_touch is
+    // an exact early-out on top of it (a pair it rejects would test false), so the full test -- ONE copy of the code, in a
+    // loop over the flagged partners -- runs only on near-contacts.
+    unsigned need = 0;  // bit p: partner with creation index p; bit G: the obstacle
     for_partners<G>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       double px = dppx_d<m>(v.x), py = dppx_d<m>(v.y), ph = dppx_d<m>(v.h);
       bool pp = dppx_i<m>((int)live) != 0;
       double dx = px - v.x, dy = py - v.y;
-      if (live && pp && !((dx * dx + dy * dy) > kU5))  // norm > LENGTH pre-check, sqrt-free
-        if (rects_intersect(v.x, v.y, v.h, px, py, kVehLength, kVehWidth, ph)) hits |= 1u << (a ^ m);
+      const bool near = live & pp & !((dx * dx + dy * dy) > kU5);  // norm > LENGTH pre-check, sqrt-free
+      need |= (near & boxes_may_touch(dx, dy, v.h, ph, 0.9 * kVehLength / 2, 0.9 * kVehWidth / 2)) ? 1u << (a ^ m) : 0u;
     });
-    bool obst_hit = false;
-    if (live) {
+    {
       double dx = kObstX - v.x, dy = kObstY - v.y;
-      if (!((dx * dx + dy * dy) > kU5)) obst_hit = rects_intersect(v.x, v.y, v.h, kObstX, kObstY, 2.0, 2.0, 0.0);
+      const bool near = live & !((dx * dx + dy * dy) > kU5);
+      need |= (near & boxes_may_touch(dx, dy, v.h, 0.0, 0.9 * 2.0 / 2, 0.9 * 2.0 / 2)) ? 1u << G : 0u;
+    }
+    unsigned hits = 0;
+    bool obst_hit = false;
+    if (__any(need != 0)) {
+      for (int p = 0; p <= G; p++) {
+        const bool t = ((need >> p) & 1u) != 0;
+        if (!__any(t)) continue;
+        const bool is_obst = p == G;
+        const int src = gb + (is_obst ? 0 : p);
+        double px = shfl_d(v.x, src), py = shfl_d(v.y, src), ph = shfl_d(v.h, src);
+        if (is_obst) { px = kObstX; py = kObstY; ph = 0.0; }
+        const double ol = is_obst ? 2.0 : kVehLength, ow = is_obst ? 2.0 : kVehWidth;
+        if (t && rects_intersect(v.x, v.y, v.h, px, py, ol, ow, ph)) {
+          if (is_obst) obst_hit = true;
+          else hits |= 1u << p;
+        }
+      }
     }
     if (__any(hits != 0 || obst_hit)) {
       // order-dependent part: creation-order double loop, min-|speed| hand-down (kinematics.py:187-196)
@@ -1509,22 +1531,38 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     if (out.min_headway) out.min_headway[e] = min_headway;
     if (out.merge_percent) out.merge_percent[e] = merge_pct;
   }
-  // ---------------- rollout metrics: block partial sums, one atomic per block ---------
+  STAMP(10);  // rewards + outputs
+  // ---------------- rollout metrics: one 64-byte partial per WAVE, no block barrier, no atomics ---------
+  // Each env's leader lane parks its 8 contributions in its own (now dead) candidate columns of the cold slots; lanes
+  // 0..7 of the wave then each sum one metric over the wave's env leaders and store the wave's slot of the partial
+  // buffer; metrics_flush_kernel (launched right behind this kernel by mm_step) folds the partials into the caller's
+  // 8 doubles.  (Round 1 used LDS atomics between two __syncthreads() + 8 global atomics per block: 15 % of a wave's
+  // lifetime parked at the barriers.)
   if (metrics) {
-    __shared__ double s_m[8];
-    if (threadIdx.x < 8) s_m[threadIdx.x] = threadIdx.x == 7 ? INFINITY : 0.0;
-    __syncthreads();
-    if (e < st.E && a == 0 && env_ok) {
-      atomicAdd(&s_m[0], reward); atomicAdd(&s_m[2], avg_speed); atomicAdd(&s_m[3], traffic_speed);
-      atomicAdd(&s_m[4], 1.0);
-      if (done) { atomicAdd(&s_m[1], crashed_bits ? 1.0 : 0.0); atomicAdd(&s_m[5], merge_pct); atomicAdd(&s_m[6], 1.0); }
-      atomic_min_d(&s_m[7], min_headway);
+    const bool lead = e < st.E && a == 0 && env_ok;
+    const double mv[8] = {lead ? reward : 0.0, (lead && done && crashed_bits) ? 1.0 : 0.0, lead ? avg_speed : 0.0,
+                          lead ? traffic_speed : 0.0, lead ? 1.0 : 0.0, (lead && done) ? merge_pct : 0.0,
+                          (lead && done) ? 1.0 : 0.0, lead ? min_headway : INFINITY};
+    if (a == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) s_cold[k < 7 ? C_B + k : C_A][tid] = mv[k];
     }
-    __syncthreads();
-    if (threadIdx.x < 7) atomicAdd(&metrics[threadIdx.x], s_m[threadIdx.x]);
-    if (threadIdx.x == 7) atomic_min_d(&metrics[7], s_m[7]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int ln = lane_id();
+    if (ln < 8) {
+      const int slot = ln < 7 ? C_B + ln : C_A, base = tid - ln;
+      double acc = ln == 7 ? INFINITY : 0.0;
+#pragma unroll
+      for (int j = 0; j < 64 / G; j++) {
+        const double x = s_cold[slot][base + j * G];
+        acc = ln == 7 ? fmin(acc, x) : acc + x;
+      }
+      metrics[(gtid >> 6) * 8 + ln] = acc;
+    }
   }
-  STAMP(10);  // rewards + outputs + metrics
+  STAMP(15);  // metrics
   // ---------------- optional re-spawn (marl/mappo.py:133-135 `if done: env.reset()`) --------------
   if (c.auto_reset && done) {
     const uint64_t seed = st.seeds[e];
@@ -1561,8 +1599,15 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   }
   STAMP(11);  // re-spawn + state store
   __syncthreads();  // every wave is done with its cold slots: the obs staging below reuses that LDS
+  STAMP(14);  // barrier (+ drain of the stores issued before it)
   observe<G, KIND, true>(c, v, a, gb, i, valid, out.obs, out.action_mask, (float *)&s_cold[0][0]);
   STAMP(12);  // observation
+#ifdef MM_STAMPS
+  {
+    const long long wv = gtid >> 6;
+    if ((threadIdx.x & 63) < 16 && wv < MM_STAMP_WAVES) g_stamps_w[wv * 16 + (threadIdx.x & 63)] += _t_acc;
+  }
+#endif
 }
 
 // reset / init / observe --------------------------------------------------------------------------
@@ -1768,16 +1813,47 @@ __global__ void qp_kernel(int n, const double *__restrict__ G, const double *__r
 
 #endif  // MM_TU <= 1
 
+// folds the per-wave metric partials of one step launch into the caller's accumulator (7 sums + 1 min): each block takes
+// 256 waves' partials (8 independent loads per thread in flight), reduces them in LDS and issues 8 atomics
+#if MM_TU <= 1
+constexpr int kFlushWaves = 256;
+__global__ __launch_bounds__(256) void metrics_flush_kernel(const double *__restrict__ partial, long long waves, double *metrics) {
+  __shared__ double s_p[32][8];
+  const int k = threadIdx.x & 7, r = threadIdx.x >> 3;
+  const long long w0 = (long long)blockIdx.x * kFlushWaves;
+  double x[kFlushWaves / 32];
+#pragma unroll
+  for (int j = 0; j < kFlushWaves / 32; j++) {
+    const long long w = w0 + r + 32 * j;
+    x[j] = w < waves ? partial[w * 8 + k] : (k == 7 ? INFINITY : 0.0);
+  }
+  double acc = k == 7 ? INFINITY : 0.0;
+#pragma unroll
+  for (int j = 0; j < kFlushWaves / 32; j++) acc = k == 7 ? fmin(acc, x[j]) : acc + x[j];
+  s_p[r][k] = acc;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    double t = k == 7 ? INFINITY : 0.0;
+    for (int j = 0; j < 32; j++) t = k == 7 ? fmin(t, s_p[j][k]) : t + s_p[j][k];
+    if (k == 7) atomic_min_d(&metrics[7], t);
+    else atomicAdd(&metrics[k], t);
+  }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // host side: C ABI
 // ------------------------------------------------------------------------------------------------
+static int group_size(int N) { return N <= 2 ? 2 : (N <= 4 ? 4 : (N <= 8 ? 8 : 16)); }
+
 struct MMHandle_ {
   MMConfig cfg;
   int E, N, device;
   unsigned char *state;
   MMStateLayout lay;
   long long first_env;
-  double *metrics;
+  double *metrics;          // caller's 8 doubles (mm_set_metrics_buffer) or NULL
+  double *metrics_partial;  // [waves of a step launch][8], device, owned by the handle
   int *dev_err;  // device error latch (MM_LATCH_* bits): hipMalloc'd at create, polled by mm_poll_errors
   char err[256];
 };
@@ -1844,6 +1920,7 @@ extern "C" int32_t mm_destroy(MMHandle h) {
   hipError_t rc = hipSetDevice(h->device);
   if (rc == hipSuccess) rc = hipDeviceSynchronize();
   if (h->dev_err) (void)hipFree(h->dev_err);
+  if (h->metrics_partial) (void)hipFree(h->metrics_partial);
   free(h);
   return rc == hipSuccess ? MM_OK : MM_ERR_DEVICE;
 }
@@ -1868,6 +1945,12 @@ extern "C" int32_t mm_set_config(MMHandle h, const MMConfig *cfg) {
 }
 extern "C" int32_t mm_set_metrics_buffer(MMHandle h, double *metrics) {
   if (!h) return MM_ERR_INVALID_ARG;
+  if (metrics && !h->metrics_partial) {  // per-wave partials of one step launch (allocated here, never inside step)
+    const long long waves = ((long long)h->E * group_size(h->N) + 63) / 64;
+    hipError_t rc = hipSetDevice(h->device);
+    if (rc == hipSuccess) rc = hipMalloc((void **)&h->metrics_partial, (size_t)waves * 8 * sizeof(double));
+    if (rc != hipSuccess) return hip_fail(h, rc, "metrics partial buffer");
+  }
   h->metrics = metrics;
   return MM_OK;
 }
@@ -1900,8 +1983,6 @@ static DevState dev_state(const MMHandle h) {
   s.A = (long long)h->E * h->N; s.E = h->E; s.N = h->N;
   return s;
 }
-static int group_size(int N) { return N <= 2 ? 2 : (N <= 4 ? 4 : (N <= 8 ? 8 : 16)); }
-
 #if MM_TU <= 1
 template <int G, int KIND>
 static void launch_reset_t(MMHandle h, int mode, const uint8_t *mask, const uint64_t *seeds, void *obs,
@@ -1967,7 +2048,7 @@ static void launch_step_t(MMHandle h, const int32_t *actions, const MMStepOut *o
   const long long threads = (long long)h->E * G;
   const unsigned grid = (unsigned)((threads + MM_STEP_BLOCK - 1) / MM_STEP_BLOCK);
   hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, MIXED, IPM>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dev_cfg(h), dev_state(h),
-                     actions, *out, h->metrics);
+                     actions, *out, h->metrics ? h->metrics_partial : nullptr);
 }
 template <int G, bool MIXED>
 static void launch_step_m(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
@@ -2054,6 +2135,11 @@ extern "C" int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *
     default: launch_step_g<16>(h, actions, out, s); break;
   }
 #endif
+  if (h->metrics) {  // fold this launch's per-wave partials into the caller's 8 doubles (same stream: ordered)
+    const long long waves = ((long long)h->E * group_size(h->N) + 63) / 64;
+    hipLaunchKernelGGL(metrics_flush_kernel, dim3((unsigned)((waves + kFlushWaves - 1) / kFlushWaves)), dim3(256), 0, s,
+                       h->metrics_partial, waves, h->metrics);
+  }
   hipError_t rc = hipGetLastError();
   return rc == hipSuccess ? MM_OK : hip_fail(h, rc, "step launch");
 }
@@ -2339,10 +2425,15 @@ extern "C" int32_t mm_policy_act(const float *obs, int64_t n, int32_t n_s, const
 
 #ifdef MM_STAMPS
 extern "C" int32_t mm_debug_read_stamps(unsigned long long *out16, int32_t reset) {
-  hipError_t rc = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16);
+  static unsigned long long *host = nullptr;
+  if (!host) host = (unsigned long long *)malloc(sizeof(unsigned long long) * MM_STAMP_WAVES * 16);
+  hipError_t rc = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps_w), sizeof(unsigned long long) * MM_STAMP_WAVES * 16);
+  for (int k = 0; k < 16; k++) out16[k] = 0;
+  for (long long w = 0; w < MM_STAMP_WAVES; w++)
+    for (int k = 0; k < 16; k++) out16[k] += host[w * 16 + k];
   if (rc == hipSuccess && reset) {
-    unsigned long long z[16] = {0};
-    rc = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z);
+    memset(host, 0, sizeof(unsigned long long) * MM_STAMP_WAVES * 16);
+    rc = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_w), host, sizeof(unsigned long long) * MM_STAMP_WAVES * 16);
   }
   return rc == hipSuccess ? MM_OK : MM_ERR_DEVICE;
 }
