@@ -239,7 +239,9 @@ def main():
                          "traffic_unit": "bytes/launch: rocprofv3 PMC passes of this command, 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction), "
                                          "committed under profiles/ (see profiles/traffic.json: source)",
                          "alg_bytes_per_launch": E * N * b_alg,
-                         "kernel": "step_kernel", "kernel_ms": kern_ms, "alg_bytes_per_agent_step": b_alg},
+                         "kernel": "step_kernel", "kernel_ms": kern_ms, "alg_bytes_per_agent_step": b_alg,
+                         "kernel_ms_note": "HIP events around mm_step on its launch stream = step_kernel + the 32-block metrics_flush_kernel "
+                                           "behind it (~4 us); rocprofv3's step_kernel average (profiles/) is that much lower"},
             "rollout_metrics": {"mean_reward": m[0] / max(m[4], 1), "crashed_episodes": m[1],
                                 "mean_speed": m[2] / max(m[4], 1), "env_steps": m[4],
                                 "mean_merge_percent": m[5] / max(m[6], 1), "episodes": m[6], "min_headway": m[7]},

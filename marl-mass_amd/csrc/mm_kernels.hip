@@ -811,12 +811,11 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   constexpr bool SHIELDED = LC && (SHIELD != MM_SHIELD_NONE);
   constexpr bool MASS = (SHIELD == MM_SHIELD_MASS);
   static_assert(!IPM || (MIXED && SHIELDED), "the IPM mode lives in the shielded general kernels");
-  // Form of the shield sweep.  MASS and the general kernels (HDVs / steer_vel) run the literal front-to-back
-  // sweep ONLY: compiled on its own it needs no VGPR spills (scratch 16 B/lane vs 248 B with both forms) and
-  // at 65536 x 8 MASS it ties the parallel fixed-point form (0.46 vs 0.45 ms) -- the coupling through the
-  // leaders' decided accelerations costs the parallel form its rounds -- while with HDVs the digital-twin case
-  // sent most sub-steps to the fallback anyway (2.30 -> 1.04 ms).  HSS has no such coupling: its parallel
-  // form is 14 % faster (0.38 vs 0.44 ms) and is what runs, with the literal sweep as fallback.
+  // Form of the shield sweep.  Every CAV-only shielded kernel (HSS and MASS) runs the parallel fixed-point form with the
+  // literal front-to-back sweep compiled in as fallback (a vehicle moving backwards in x) and as the validation form
+  // (debug_flags bit0); the general kernels (HDVs / steer_vel) and the IPM kernels carry the literal sweep ONLY
+  // (kSerialOnly): the HDV "digital twin" branch is only expressible there, and the IPM solves one QP per vehicle per
+  // sub-step as the reference does.  See DESIGN.md section 2.
 #ifdef MM_SERIAL_ALL  // tuning switch: every shielded kernel carries the literal sweep only
   constexpr bool kSerialOnly = true;
 #else

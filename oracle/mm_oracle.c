@@ -11,9 +11,11 @@
  * and only as the checker / reported CPU baseline.  The product path never routes through it.
  *
  * Parity pin: checked against golden vectors generated from the reference itself
- * (tools/gen_golden.py -> tests/golden/, test_oracle_golden.py).  The shield QP is solved by its
- * exact KKT closed form; the reference's cvxopt 1.2.7 interior-point iterate is NOT available in
- * this image, so the raw solver output is "parity unpinned" (see DESIGN.md).
+ * (tools/gen_golden.py -> tests/golden/, test_oracle_golden.py).  The shield QP has two modes: its exact
+ * KKT closed form, and qp_ipm -- a restatement of cvxopt's coneqp algorithm pinned bit for bit against the
+ * reference-side stand-in that answered solvers.qp while the reference produced the ipm_* tapes.  cvxopt 1.2.7
+ * itself is NOT available in this image: against the real binary the raw solver output (its BLAS/LAPACK
+ * rounding) stays "parity unpinned" (see DESIGN.md section 3).
  *
  * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (oracle/Makefile).  -ffp-contract=off
  * keeps a*b+c as two roundings like CPython/numpy scalar arithmetic.

@@ -186,9 +186,8 @@ def test_random_rollout_vs_oracle(case):
 
 @pytest.mark.parametrize("safety,N", [("cbf-avs_cint", 8), ("cbf-avs_cint", 4), ("cbf-avs_cint", 11), ("cbf-avs", 6), ("cbf-cav", 8)])
 def test_parallel_sweep_equals_literal_serial_sweep(safety, N):
-    """The parallel fixed-point form of the shield sweep (what the CAV-only HSS kernels run) vs the literal
-    front-to-back sweep (debug_flags bit0), LC-heavy action tape: identical bits everywhere.  (MASS kernels
-    carry the literal sweep only; for them the flag is a no-op and the case checks just that.)"""
+    """The parallel fixed-point form of the shield sweep (what the CAV-only HSS and MASS kernels run) vs the literal
+    front-to-back sweep (debug_flags bit0), LC-heavy action tape: identical bits everywhere."""
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5},
               cbf_eta=0.03125, cbf_tau=0.5, seed=4242, auto_reset=True, trace=True)
     E = 2048

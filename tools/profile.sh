@@ -16,4 +16,8 @@ for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "S
   rocprofv3 --pmc $c --output-format csv -d "$O/pmc$i" -o pmc -- python3 "$R/bench.py" --no-cpu-baseline --steps 20 --warmup 5 "$@" > /dev/null 2> "$O/pmc$i.err"
   echo "pmc pass $i ($c) done"
 done
+# counter calibration on known byte counts (8 B/lane doubles, 1 B/lane bytes, float2 runs)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d "$O/calib_$c" -o pmc -- "$R/tools/ubench/fetch_calib" > "$O/calib_$c.txt" 2> "$O/calib_$c.err" || true
+done
 python3 "$R/tools/profile_summary.py" "$O" "$@"
