@@ -810,19 +810,19 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   constexpr bool LC = (KIND == MM_ENV_V1);
   constexpr bool SHIELDED = LC && (SHIELD != MM_SHIELD_NONE);
   constexpr bool MASS = (SHIELD == MM_SHIELD_MASS);
-  static_assert(!IPM || (MIXED && SHIELDED), "the IPM mode lives in the shielded general kernels");
+  static_assert(!IPM || SHIELDED, "the IPM mode lives in shielded kernels");
   // Form of the shield sweep.  Every CAV-only shielded kernel (HSS and MASS) runs the parallel fixed-point form with the
   // literal front-to-back sweep compiled in as fallback (a vehicle moving backwards in x) and as the validation form
   // (debug_flags bit0); the general kernels (HDVs / steer_vel) and the IPM kernels carry the literal sweep ONLY
   // (kSerialOnly): the HDV "digital twin" branch is only expressible there, and the IPM solves one QP per vehicle per
   // sub-step as the reference does.  See DESIGN.md section 2.
 #ifdef MM_SERIAL_ALL  // tuning switch: every shielded kernel carries the literal sweep only
-  constexpr bool kSerialOnly = true;
+  constexpr bool kSerialOnly = true || IPM;
 #else
 #ifdef MM_SERIAL_MASS  // tuning switch: MASS in the literal form at every size
-  constexpr bool kSerialOnly = MIXED || MASS;
+  constexpr bool kSerialOnly = MIXED || MASS || IPM;
 #else
-  constexpr bool kSerialOnly = MIXED;
+  constexpr bool kSerialOnly = MIXED || IPM;  // the IPM solves one QP per vehicle per sub-step, in sweep order, as the reference does
 #endif
 #endif
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2062,10 +2062,19 @@ static void launch_step_m(MMHandle h, const int32_t *actions, const MMStepOut *o
     default: launch_step_t<G, MM_ENV_V1, MM_SHIELD_NONE, MIXED>(h, actions, out, s);
   }
 }
+template <int G, bool MIXED>
+static void launch_step_ipm_gm(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+  if (h->cfg.shield == MM_SHIELD_MASS) launch_step_t<G, MM_ENV_V1, MM_SHIELD_MASS, MIXED, true>(h, actions, out, s);
+  else launch_step_t<G, MM_ENV_V1, MM_SHIELD_HSS, MIXED, true>(h, actions, out, s);
+}
+static bool needs_general(const MMHandle h) {  // HDVs can appear, or steer_vel lateral control: the kernels that carry IDM / MOBIL
+  return h->cfg.n_hdv > 0 || (h->cfg.traffic_density > 0 && h->cfg.mixed_traffic) ||
+         (h->cfg.env_kind == MM_ENV_V1 && h->cfg.lateral_control == MM_LATERAL_STEER_VEL);
+}
 template <int G>
 static void launch_step_ipm_g(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
-  if (h->cfg.shield == MM_SHIELD_MASS) launch_step_t<G, MM_ENV_V1, MM_SHIELD_MASS, true, true>(h, actions, out, s);
-  else launch_step_t<G, MM_ENV_V1, MM_SHIELD_HSS, true, true>(h, actions, out, s);
+  if (needs_general(h)) launch_step_ipm_gm<G, true>(h, actions, out, s);
+  else launch_step_ipm_gm<G, false>(h, actions, out, s);  // CAV-only: the lean literal-sweep kernel around the same IPM
 }
 // mixed traffic (cfg.n_hdv > 0) and steer_vel run the "general" kernels that carry the IDM/MOBIL code; the MM_QP_IPM
 // fidelity mode has its own (general, literal-sweep) kernels; CAV-only batches keep the leaner instantiation.
@@ -2105,8 +2114,7 @@ static void launch_step_g(MMHandle h, const int32_t *actions, const MMStepOut *o
 #else
     launch_step_ipm_g<G>(h, actions, out, s);
 #endif
-  else if (h->cfg.n_hdv > 0 || (h->cfg.traffic_density > 0 && h->cfg.mixed_traffic) ||
-           (h->cfg.env_kind == MM_ENV_V1 && h->cfg.lateral_control == MM_LATERAL_STEER_VEL))
+  else if (needs_general(h))
 #if MM_TU == 1
     mm_launch_step_general(h, actions, out, s);
 #else

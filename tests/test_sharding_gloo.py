@@ -68,6 +68,60 @@ def test_two_rank_shards_equal_single_batch(tmp_path):
     assert float(m[4]) == E * STEPS and float(m[6]) >= E  # env-steps counted, every episode finished once
 
 
+def _worker_hip(rank, world, port, out_dir):
+    """One rank of the HIP backend: its own process, its own handle on cuda:0 (the 1-GPU box has no second device; on the
+    node every rank has its own GPU and the collective is RCCL), metrics reduced over gloo through host copies."""
+    sys.path.insert(0, REPO)
+    from marl_mass_amd import VecMergeEnv, reduce_rollout_metrics, shard_range
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    EH = 4096
+    first, count = shard_range(EH, rank, world)
+    env = VecMergeEnv(count, 8, device="cuda:0", first_env=first, **dict(KW, seed=1000))
+    m = env.enable_metrics()
+    env.reset()
+    g = torch.Generator().manual_seed(5)
+    p = torch.tensor([0.1, 0.5, 0.2, 0.1, 0.1])
+    for _ in range(STEPS):
+        a = torch.multinomial(p, EH * 8, True, generator=g).view(EH, 8).int()
+        env.step(a[first:first + count].contiguous().cuda())
+    reduce_rollout_metrics(m)
+    torch.save({"f64": env.f64.cpu(), "u8": env.u8.cpu(), "i32": env.env_i32.cpu(), "metrics": m.cpu(), "first": first, "count": count},
+               os.path.join(out_dir, "hip_rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_rank_shards_equal_single_batch_hip(tmp_path):
+    """The N > 1 path on the product backend: two rank processes (each with its own library handle, shard and
+    `first_env`), metric all-reduce, against one process holding the whole batch -- every bit of state, and the metrics."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_hip, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from marl_mass_amd import VecMergeEnv
+    EH = 4096
+    full = VecMergeEnv(EH, 8, device="cuda:0", **dict(KW, seed=1000))
+    m = full.enable_metrics()
+    full.reset()
+    g = torch.Generator().manual_seed(5)
+    p = torch.tensor([0.1, 0.5, 0.2, 0.1, 0.1])
+    for _ in range(STEPS):
+        full.step(torch.multinomial(p, EH * 8, True, generator=g).view(EH, 8).int().cuda())
+    parts = [torch.load(os.path.join(str(tmp_path), "hip_rank%d.pt" % r)) for r in range(2)]
+    for part in parts:
+        sl = slice(part["first"], part["first"] + part["count"])
+        assert torch.equal(part["f64"].nan_to_num(), full.f64[:, sl].cpu().nan_to_num())
+        assert torch.equal(part["u8"], full.u8[:, sl].cpu()) and torch.equal(part["i32"], full.env_i32[:, sl].cpu())
+        assert torch.allclose(part["metrics"][:7], m.cpu()[:7], rtol=1e-12, atol=0)
+        assert float(part["metrics"][7]) == float(m[7])
+    assert float(m[4]) == EH * STEPS
+
+
 def test_shard_range_covers_batch():
     from marl_mass_amd import shard_range
     for total, world in ((65536, 8), (10, 3), (7, 8)):
