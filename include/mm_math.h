@@ -216,4 +216,23 @@ MMM_FN double mmm_log(double x) {
   return fma(de, MMM_LN2_HI, l + de * MMM_LN2_LO);
 }
 
+/* ---- angle-sum forms used by the DEVICE arithmetic of the bicycle step (mm_kernels.hip: predict; oracle math mode 1) ----
+ * The reference evaluates np.arctan(1/2 tan(delta)), np.cos(psi + beta), np.sin(psi + beta), np.sin(beta),
+ * np.cos(psi' + beta) and the three corner angles alpha + psi', -alpha + psi' as eleven separate libm calls per vehicle
+ * step (kinematics.py:122-141, safe_controller.py:151-172, controller.py:257-267).  With sin / cos of the heading carried
+ * along, all of them follow from ONE sincos of the steering angle and ONE of the new heading:
+ *   t = tan(beta) = 1/2 tan(delta);  cos(beta) = 1 / sqrt(1 + t^2),  sin(beta) = t / sqrt(1 + t^2)   (|beta| < pi/2)
+ *   cos(a + b) = cos a cos b - sin a sin b,   sin(a + b) = sin a cos b + cos a sin b.
+ * Same mathematical quantities, a few ulp from the separately evaluated ones -- the same class of deviation as these
+ * functions themselves have from libm; both users of this header evaluate exactly these expressions. */
+#define MMM_CORNER_COS 0x1.db614bfce6a6ap-1 /* cos(atan(0.4)) = 1 / sqrt(1.16) = 0.9284766908852593 */
+#define MMM_CORNER_SIN 0x1.7c4dd663ebb88p-2 /* sin(atan(0.4)) = 0.4 / sqrt(1.16) = 0.3713906763541037 */
+MMM_FN double mmm_cos_sum(double sa, double ca, double sb, double cb) { return ca * cb - sa * sb; }
+MMM_FN double mmm_sin_sum(double sa, double ca, double sb, double cb) { return sa * cb + ca * sb; }
+MMM_FN void mmm_slip_sincos(double t, double *sb, double *cb) { /* beta = atan(t) */
+  const double r = sqrt(1.0 + t * t);
+  *cb = 1.0 / r;
+  *sb = t / r;
+}
+
 #endif /* MM_MATH_H */

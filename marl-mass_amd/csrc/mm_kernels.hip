@@ -244,10 +244,11 @@ MM_DEV void clip_actions(Veh &v, bool lc_vehicle) {
 
 // controller.py:257-267 get_corner("L"/"R") + lane.on_lane of those corners on `lane`
 // -> bit0: the front-left corner is off `lane`, bit1: the front-right one
-MM_DEV int corner_flags(double x, double y, double h, int lane) {
-  double cx = x + (kCornerLen * mmm_cos(kCornerAlpha + h));
-  double cyL = y - (kCornerLen * mmm_sin(kCornerAlpha + h)) + 0.01;
-  double cyR = y - (kCornerLen * mmm_sin(-kCornerAlpha + h)) + 0.01;
+// (the three corner angles alpha + h, -alpha + h as angle sums from sin h, cos h: include/mm_math.h "angle-sum forms")
+MM_DEV int corner_flags(double x, double y, double sh, double ch, int lane) {
+  double cx = x + (kCornerLen * mmm_cos_sum(MMM_CORNER_SIN, MMM_CORNER_COS, sh, ch));
+  double cyL = y - (kCornerLen * mmm_sin_sum(MMM_CORNER_SIN, MMM_CORNER_COS, sh, ch)) + 0.01;
+  double cyR = y - (kCornerLen * mmm_sin_sum(-MMM_CORNER_SIN, MMM_CORNER_COS, sh, ch)) + 0.01;
   double s = cx - lane_sx(lane);
   double off = (lane == MM_LANE_KB0) ? kSineAmp * mmm_sin(kSinePuls * s + kSinePhase) : 0.0;
   bool lon = (-kVehLength <= s && s < lane_len(lane) + kVehLength);
@@ -263,27 +264,33 @@ MM_DEV int pose_code(int lane, int nl, int off) { return lane | nl << 3 | off <<
 // Predicted post-state of Vehicle.step for a given steering (kinematics.py:122-141,
 // safe_controller.py:151-172): everything that does not depend on the acceleration.
 struct Cand {
-  double x, y, h, gvx, cpsi;
+  double x, y, h, gvx, cpsi, spsi;  // cpsi / spsi: cos / sin of the new heading
   int lane;  // closest lane of the post-state
   int pk;    // its pose code (SHIELDED only)
 };
 // CORNERS: the front-corner bits are read by MASS only (constrain_adj, can_abort_lc): HSS kernels skip them
+// Device arithmetic of the step (the oracle's math mode 1 evaluates the same expressions): with sin / cos of the current
+// heading carried along (sh, ch), the reference's eleven trigonometric calls -- arctan(1/2 tan delta), cos / sin(psi + beta),
+// sin(beta), cos(psi' + beta), cos(psi') and the three corner angles -- become ONE sincos of the steering angle and ONE of
+// the new heading plus angle sums; beta itself is never formed (include/mm_math.h, "angle-sum forms").
 template <int KIND, bool SHIELDED, bool CORNERS = SHIELDED>
-MM_DEV Cand predict(const Veh &v, double steer, double dt, bool sv = false) {
+MM_DEV Cand predict(const Veh &v, double steer, double sh, double ch, double dt, bool sv = false) {
   Cand c;
   // "steer_vel" (safe_controller.py:124-150): the slip angle comes from the steering-angle STATE and the
   // heading advances by d_heading without the dt factor (sic, :135)
-  double beta = mmm_atan(1.0 / 2 * mmm_tan(sv ? v.sang : steer));
-  double vx = v.v * mmm_cos(v.h + beta), vy = v.v * mmm_sin(v.h + beta);
+  double ss, cs, sb, cb;
+  mmm_sincos(sv ? v.sang : steer, &ss, &cs);
+  mmm_slip_sincos(1.0 / 2 * (ss / cs), &sb, &cb);  // beta = atan(1/2 tan(delta)): its sin and cos
+  double vx = v.v * mmm_cos_sum(sh, ch, sb, cb), vy = v.v * mmm_sin_sum(sh, ch, sb, cb);
   c.x = v.x + vx * dt;
   c.y = v.y + vy * dt;
-  const double d_heading = MM_DIVC(v.v * mmm_sin(beta), 2.5);  // / (LENGTH / 2)
+  const double d_heading = MM_DIVC(v.v * sb, 2.5);  // / (LENGTH / 2)
   c.h = v.h + (sv ? d_heading : d_heading * dt);
-  c.gvx = (KIND == MM_ENV_V1) ? mmm_cos(c.h + beta) : 0.0;
+  mmm_sincos(c.h, &c.spsi, &c.cpsi);
+  c.gvx = (KIND == MM_ENV_V1) ? mmm_cos_sum(c.spsi, c.cpsi, sb, cb) : 0.0;
   c.lane = closest_lane(c.x, c.y, c.h);  // on_state_update kinematics.py:154-159
-  c.cpsi = (KIND == MM_ENV_V1) ? mmm_cos(c.h) : 0.0;
   c.pk = c.lane;
-  if (SHIELDED) c.pk = pose_code(c.lane, next_lane(c.lane, c.x, c.y), CORNERS ? corner_flags(c.x, c.y, c.h, c.lane) : 0);
+  if (SHIELDED) c.pk = pose_code(c.lane, next_lane(c.lane, c.x, c.y), CORNERS ? corner_flags(c.x, c.y, c.spsi, c.cpsi, c.lane) : 0);
   return c;
 }
 
@@ -392,11 +399,12 @@ MM_DEV int spawn_vehicle(Veh &v, int a, int n_cav, int n_hdv, uint64_t seed, uin
 // ------------------------------------------------------------------------------------------------
 template <int G, int KIND, bool LEND = false>
 MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, bool valid, void *obs,
-                    uint8_t *avail, float *stage = nullptr) {
+                    uint8_t *avail, float *stage = nullptr, const double *sincos_h = nullptr) {
   constexpr int F = (KIND == MM_ENV_V1) ? 6 : 5;
   const bool ctrl = v.present && v.kind != 2;  // only controlled vehicles observe / have an action mask
   double sps, cps;
-  mmm_sincos(v.h, &sps, &cps);
+  if (sincos_h) { sps = sincos_h[0]; cps = sincos_h[1]; }  // the step kernel carries sin / cos of the heading along
+  else mmm_sincos(v.h, &sps, &cps);
   const double vx = v.v * cps, vy = v.v * sps;  // Vehicle.velocity kinematics.py:215-217
   const double sx = lane_sx(v.lane);
   // pass 1: sort keys of close_vehicles_to (road.py:257-267): |lane_distance_to|, inf if not within 180 m
@@ -859,22 +867,22 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   steps += 1;  // abstract.py:457
 
   // derived per-vehicle registers the shield keeps current across sub-steps
-  double cpsi = ((SHIELDED || MIXED) && v.present) ? mmm_cos(v.h) : 1.0;
+  double cpsi = 1.0, spsi = 0.0;  // cos / sin of my current heading (every kernel: the bicycle step is built on them)
+  if (v.present) mmm_sincos(v.h, &spsi, &cpsi);
   int pk_self = v.lane;  // pose code of my current (pre-step) pose
-  if (SHIELDED && v.present) pk_self = pose_code(v.lane, next_lane(v.lane, v.x, v.y), MASS ? corner_flags(v.x, v.y, v.h, v.lane) : 0);
+  if (SHIELDED && v.present) pk_self = pose_code(v.lane, next_lane(v.lane, v.x, v.y), MASS ? corner_flags(v.x, v.y, spsi, cpsi, v.lane) : 0);
 
   // Register relief: lane-private values that are written once and read rarely live in LDS ("cold"
   // slots, one column per thread) instead of being spilled to scratch by the compiler (measured: each
   // 100 B/lane of scratch costs ~8 % of the kernel): the LC-veto candidate B, the history records,
   // the previous safe action, the target speed, and the 7..15 sort keys of the classification pass.
   // (C_GU0 / C_GU1: parallel form only -- the g*u product of my pre- / post-step record for the askers' gather)
-  enum { C_B = 0, C_H1X = 7, C_H1VX, C_H2X, C_H2VX, C_SSTEER, C_SACC, C_TSPEED, C_A = 14, C_GU0 = 21, C_GU1 = 22, kColdB = 23 };
-  // unshielded kernels use only slots 7..13 (+ the obs staging: 15 slots); the sort keys are a parallel-form temporary
-  // kRoomy: parallel-form kernels with 8-lane groups or smaller have LDS to spare for two more per-lane values
-  // (cos(heading) and g.vx of the current pose: read two or three times per pass)
-  constexpr bool kRoomy = SHIELDED && !kSerialOnly && G <= 8;
+  enum { C_B = 0, C_H1X = 8, C_H1VX, C_H2X, C_H2VX, C_SSTEER, C_SACC, C_TSPEED, C_A = 15, C_GU0 = 23, C_GU1 = 24, kColdB = 25 };
+  // candidates occupy 8 slots each (x, y, h, g.vx, cos h, steering, pose code, sin h); unshielded kernels use only slots
+  // 8..14 (+ the obs staging: 15 slots); the sort keys are a parallel-form temporary
+  constexpr bool kRoomy = false;  // (round 1 parked cos(heading) / g.vx in LDS as well: no longer measurable, 0.332 ms either way)
   constexpr int C_CPSI = kColdB + G - 1, C_GVX = C_CPSI + 1;
-  constexpr int kColdN = !SHIELDED ? 15 : (kSerialOnly ? 21 : kColdB + G - 1 + (kRoomy ? 2 : 0));
+  constexpr int kColdN = !SHIELDED ? 15 : (kSerialOnly ? 23 : kColdB + G - 1 + (kRoomy ? 2 : 0));
   static_assert(kColdN * MM_STEP_BLOCK * 8 >= (MM_STEP_BLOCK / 64) * 64 * 30 * 4, "the obs staging must fit in the cold slots");
   __shared__ double s_cold[kColdN][MM_STEP_BLOCK];
   const int tid = threadIdx.x;
@@ -1001,13 +1009,13 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     Cand cA;
     memset(&cA, 0, sizeof cA);
     const bool shield_on = SHIELDED && live && !hdv && v.hist_len >= 2;  // gate safe_controller.py:232-239
-    if (live) cA = predict<KIND, SHIELDED, MASS>(v, v.act_steer, dt, sv && !hdv);
+    if (live) cA = predict<KIND, SHIELDED, MASS>(v, v.act_steer, spsi, cpsi, dt, sv && !hdv);
     auto park = [&](auto base_c, const Cand &cc, double steer) {  // a candidate's LDS image (shielded kernels only)
       constexpr int base = decltype(base_c)::value;
       if constexpr (SHIELDED) {
         s_cold[base + 0][tid] = cc.x; s_cold[base + 1][tid] = cc.y; s_cold[base + 2][tid] = cc.h;
         s_cold[base + 3][tid] = cc.gvx; s_cold[base + 4][tid] = cc.cpsi; s_cold[base + 5][tid] = steer;
-        s_cold[base + 6][tid] = (double)cc.pk;
+        s_cold[base + 6][tid] = (double)cc.pk; s_cold[base + 7][tid] = cc.spsi;
       }
     };
     park(std::integral_constant<int, C_A>{}, cA, v.act_steer);
@@ -1024,7 +1032,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         if (needB && !haveB) {
           double steerB = steering_control(v.x, v.y, v.h, v.v, v.lane);
           if (sv) steerB = steer_vel_command(steerB, v.sang);
-          park(std::integral_constant<int, C_B>{}, predict<KIND, true, MASS>(v, steerB, dt, sv), steerB);
+          park(std::integral_constant<int, C_B>{}, predict<KIND, true, MASS>(v, steerB, spsi, CPSI(), dt, sv), steerB);
           haveB = true;
         }
       }
@@ -1037,7 +1045,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         const int base = useB ? C_B : C_A;  // both candidates sit in LDS; A's registers are free meanwhile
         Cand cc;
         cc.x = s_cold[base + 0][tid]; cc.y = s_cold[base + 1][tid]; cc.h = s_cold[base + 2][tid];
-        cc.gvx = s_cold[base + 3][tid]; cc.cpsi = s_cold[base + 4][tid];
+        cc.gvx = s_cold[base + 3][tid]; cc.cpsi = s_cold[base + 4][tid]; cc.spsi = s_cold[base + 7][tid];
         const int pk = (int)s_cold[base + 6][tid];
         cc.pk = pk; cc.lane = pk & 7;
         return cc;
@@ -1322,7 +1330,8 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         if (v.hist_len < 2) v.hist_len++;
       }
       if constexpr (kRoomy) s_cold[C_CPSI][tid] = cc.cpsi;
-      else if (SHIELDED || MIXED) cpsi = cc.cpsi;
+      else cpsi = cc.cpsi;
+      spsi = cc.spsi;
       if (SHIELDED) pk_self = cc.pk;
     }
 
@@ -1500,7 +1509,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     double h2d = hd;
     if (fabs(kObstY - v.y) <= 2 && kObstX > v.x) { double dd = kObstX - v.x; if (dd < h2d) h2d = dd; }
     h2d = h2d - kVehLength;
-    double vx = v.v * mmm_cos(v.h);
+    double vx = v.v * cpsi;  // cos(heading), carried along
     th = h2d / (vx > 1 ? vx : 1);
   }
   const double min_headway = group_min_d<G>(th);
@@ -1544,14 +1553,14 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
                           (lead && done) ? 1.0 : 0.0, lead ? min_headway : INFINITY};
     if (a == 0) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) s_cold[k < 7 ? C_B + k : C_A][tid] = mv[k];
+      for (int k = 0; k < 8; k++) s_cold[C_B + k][tid] = mv[k];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int ln = lane_id();
     if (ln < 8) {
-      const int slot = ln < 7 ? C_B + ln : C_A, base = tid - ln;
+      const int slot = C_B + ln, base = tid - ln;
       double acc = ln == 7 ? INFINITY : 0.0;
 #pragma unroll
       for (int j = 0; j < 64 / G; j++) {
@@ -1578,6 +1587,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     }
     if (spawn) {
       v = nv;
+      spsi = 0.0; cpsi = 1.0;  // heading 0
       s_cold[C_H1X][tid] = v.h1x; s_cold[C_H1VX][tid] = v.h1vx; s_cold[C_H2X][tid] = v.h2x; s_cold[C_H2VX][tid] = v.h2vx;
       s_cold[C_SSTEER][tid] = v.safe_steer; s_cold[C_SACC][tid] = v.safe_acc; s_cold[C_TSPEED][tid] = v.tspeed;
     }
@@ -1599,7 +1609,8 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   STAMP(11);  // re-spawn + state store
   __syncthreads();  // every wave is done with its cold slots: the obs staging below reuses that LDS
   STAMP(14);  // barrier (+ drain of the stores issued before it)
-  observe<G, KIND, true>(c, v, a, gb, i, valid, out.obs, out.action_mask, (float *)&s_cold[0][0]);
+  const double sc_h[2] = {spsi, cpsi};
+  observe<G, KIND, true>(c, v, a, gb, i, valid, out.obs, out.action_mask, (float *)&s_cold[0][0], sc_h);
   STAMP(12);  // observation
 #ifdef MM_STAMPS
   {
@@ -1673,9 +1684,10 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
   const bool ctrl = v.present && !hdv;
   if (valid) { v.act_steer = act_steer[i]; v.act_acc = act_acc[i]; }
   const bool on = ctrl && SHIELD != MM_SHIELD_NONE && v.hist_len >= 2;  // gate safe_controller.py:229-239
-  const double cpsi = v.present ? mmm_cos(v.h) : 1.0;
+  double cpsi = 1.0, spsi = 0.0;
+  if (v.present) mmm_sincos(v.h, &spsi, &cpsi);
   int pk_self = v.lane;
-  if (v.present) pk_self = pose_code(v.lane, next_lane(v.lane, v.x, v.y), MASS ? corner_flags(v.x, v.y, v.h, v.lane) : 0);
+  if (v.present) pk_self = pose_code(v.lane, next_lane(v.lane, v.x, v.y), MASS ? corner_flags(v.x, v.y, spsi, cpsi, v.lane) : 0);
   // every other vehicle is seen in its CURRENT state: records [-2], last safe_action, g.vx as stored
   double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
   int j_ol = -1, j_oa = -1, j_oar = -1;

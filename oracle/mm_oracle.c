@@ -327,6 +327,14 @@ static void mdp_act(Veh *v, int action, int is_lc) {
 static void get_corner(const Veh *v, int dir, double *cx, double *cy) {
   const double CORNER_LEN = sqrt((VEH_WIDTH / 2) * (VEH_WIDTH / 2) + (VEH_LENGTH / 2) * (VEH_LENGTH / 2)) + 0.0075;
   const double CORNER_ALPHA = m_atan(VEH_WIDTH / VEH_LENGTH);
+  if (g_math_mode) { /* device arithmetic: angle sums from sin / cos of the heading (include/mm_math.h) */
+    double sh, ch;
+    mmm_sincos(v->heading, &sh, &ch);
+    *cx = v->x + (CORNER_LEN * mmm_cos_sum(MMM_CORNER_SIN, MMM_CORNER_COS, sh, ch));
+    if (dir == 0) *cy = v->y - (CORNER_LEN * mmm_sin_sum(MMM_CORNER_SIN, MMM_CORNER_COS, sh, ch)) + 0.01;
+    else *cy = v->y - (CORNER_LEN * mmm_sin_sum(-MMM_CORNER_SIN, MMM_CORNER_COS, sh, ch)) + 0.01;
+    return;
+  }
   *cx = v->x + (CORNER_LEN * m_cos(CORNER_ALPHA + v->heading));
   if (dir == 0) *cy = v->y - (CORNER_LEN * m_sin(CORNER_ALPHA + v->heading)) + 0.01;
   else *cy = v->y - (CORNER_LEN * m_sin(-CORNER_ALPHA + v->heading)) + 0.01;
@@ -913,6 +921,30 @@ static int vehicle_step(const MMConfig *cfg, Env *e, int i, double dt) {
     rc = safety_layer(cfg, e, i, dt, &acc, &steer);
   if (is_lc) { v->safe_steer = steer; v->safe_acc = acc; }
   double beta;
+  if (g_math_mode) {
+    /* device arithmetic (math mode 1): the same bicycle step with the eleven trigonometric calls folded into one sincos
+     * of the steering angle and one of the new heading (include/mm_math.h, "angle-sum forms"); beta itself is never formed */
+    const int sv = is_lc && v->steer_vel;
+    double ss, cs, sb, cb, sh, ch;
+    mmm_sincos(sv ? v->steer_angle : steer, &ss, &cs);
+    mmm_slip_sincos(1.0 / 2 * (ss / cs), &sb, &cb);
+    mmm_sincos(v->heading, &sh, &ch);
+    double vx = v->speed * mmm_cos_sum(sh, ch, sb, cb);
+    double vy = v->speed * mmm_sin_sum(sh, ch, sb, cb);
+    v->x += vx * dt;
+    v->y += vy * dt;
+    double d_heading = v->speed * sb / (VEH_LENGTH / 2);
+    v->heading += sv ? d_heading : d_heading * dt;
+    v->speed += acc * dt;
+    if (sv) v->steer_angle += steer * dt;
+    v->speed = v->speed > 0 ? v->speed : 0;
+    if (is_lc) {
+      double sh2, ch2;
+      mmm_sincos(v->heading, &sh2, &ch2);
+      v->g_vx = mmm_cos_sum(sh2, ch2, sb, cb);
+    }
+    beta = 0;
+  } else
   if (is_lc && v->steer_vel) { /* safe_controller.py:124-150: 2nd-order steering response */
     beta = m_atan(1.0 / 2 * m_tan(v->steer_angle));
     double vx = v->speed * m_cos(v->heading + beta);
@@ -932,8 +964,10 @@ static int vehicle_step(const MMConfig *cfg, Env *e, int i, double dt) {
     v->heading += v->speed * m_sin(beta) / (VEH_LENGTH / 2) * dt;
     v->speed += acc * dt;
   }
-  v->speed = v->speed > 0 ? v->speed : 0; /* max(0, speed) */
-  if (is_lc) v->g_vx = m_cos(v->heading + beta);
+  if (!g_math_mode) {
+    v->speed = v->speed > 0 ? v->speed : 0; /* max(0, speed) */
+    if (is_lc) v->g_vx = m_cos(v->heading + beta);
+  }
   v->lane = closest_lane(v->x, v->y, v->heading); /* on_state_update kinematics.py:154-159 */
   if (is_lc || (hdv && cfg->env_kind == MM_ENV_V1)) { /* log_step safe_controller.py:187-201 / behavior.py:505-521 (IDMVehicleHist) */
     memcpy(v->h2, v->h1, sizeof v->h1);
