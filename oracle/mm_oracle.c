@@ -32,7 +32,8 @@
 /*
  * Elementary-function mode.  0 (default): the platform libm, i.e. the reference's own arithmetic
  * (CPython/numpy call the same libm) -- this is the mode pinned bit-tight to the golden tapes.
- * 1: the bit-reproducible functions of include/mm_math.h, identical to what the HIP kernels
+ * 1: the DEVICE arithmetic -- the bit-reproducible functions of include/mm_math.h and, in the bicycle step and the corner
+ * points, its angle-sum forms (one sincos of the steering angle, one of the new heading) -- identical to what the HIP kernels
  * evaluate, so that HIP-vs-oracle comparisons can demand equality of every bit (decisions such as
  * the LC veto are rounding-noise knife-edges, see mm_math.h).  Mode 1 is itself checked against
  * the golden tapes (<= 1e-9, same flags) in tests/test_oracle_golden.py.
