@@ -153,11 +153,13 @@ MMM_FN double mmm_tan(double x) {
   mmm_sincos(x, &s, &c);
   return s / c;
 }
-/* atan on [0, 1]: nearest breakpoint c = j/4, t = (x - c) / (1 + x c), |t| <= 1/8, Taylor to t^21 */
-MMM_FN double mmm_atan01(double ax, double *lo_out) {
-  int j = (int)(4.0 * ax + 0.5);
+/* atan(num / den) for 0 <= num <= den, den > 0, WITHOUT forming the ratio: nearest breakpoint c = j/4 of q = num/den
+ * (q >= (k - 1/2)/4  <=>  num >= ((k - 1/2)/4) den), t = (q - c) / (1 + q c) = (num - c den) / (den + c num), |t| <= 1/8,
+ * Taylor to t^21.  One division where asin(x) = atan2(|x|, sqrt((1-|x|)(1+|x|))) used to need two (the ratio, then t). */
+MMM_FN double mmm_atan_ratio(double num, double den, double *lo_out) {
+  const int j = (num >= 0.125 * den) + (num >= 0.375 * den) + (num >= 0.625 * den) + (num >= 0.875 * den);
   double c = 0.25 * (double)j;
-  double t = (ax - c) / fma(ax, c, 1.0); /* j == 0: (ax - 0) / 1 == ax exactly, no special case needed */
+  double t = (num - c * den) / (den + c * num); /* j == 0: num / den */
   double z = t * t;
   double p = MMM_A10;
   p = mmm_fma_c(p, z, MMM_A9); p = mmm_fma_c(p, z, MMM_A8); p = mmm_fma_c(p, z, MMM_A7); p = mmm_fma_c(p, z, MMM_A6);
@@ -170,22 +172,27 @@ MMM_FN double mmm_atan01(double ax, double *lo_out) {
   return hi + (pt + lo);
 }
 MMM_FN double mmm_atan(double x) {
-  double ax = fabs(x), lo, z = ax;
-  const int inv = ax > 1.0;
-  if (inv) z = 1.0 / ax; /* rare on this path (arguments are slopes < 1): a skipped branch, one atan01 body */
-  double r = mmm_atan01(z, &lo);
+  double ax = fabs(x), lo;
+  const int inv = ax > 1.0; /* atan(ax) = pi/2 - atan(1 / ax): the ratio 1 / ax is never formed either */
+  double r = mmm_atan_ratio(inv ? 1.0 : ax, inv ? ax : 1.0, &lo);
   if (inv) r = MMM_PIO2_HI - (r - MMM_PIO2_LO);
   return x < 0 ? -r : r;
 }
-/* asin(x) = atan2(|x|, sqrt((1-|x|)(1+|x|))), |x| <= 1 */
-MMM_FN double mmm_asin(double x) {
+/* asin(x) = atan2(|x|, sqrt((1-|x|)(1+|x|))), |x| <= 1; *w_out = sqrt((1-|x|)(1+|x|)) = cos(asin x), which the bicycle
+ * step reuses (sin / cos of a steering angle that IS an arcsine: no second range reduction, no polynomials) */
+MMM_FN double mmm_asin_w(double x, double *w_out) {
   double y = fabs(x), lo;
   double w = sqrt((1.0 - y) * (1.0 + y));
+  *w_out = w;
   const int direct = y <= w;
-  double r = mmm_atan01((direct ? y : w) / (direct ? w : y), &lo); /* one division, one polynomial */
+  double r = mmm_atan_ratio(direct ? y : w, direct ? w : y, &lo); /* one division, one polynomial */
   if (!direct) r = MMM_PIO2_HI - (r - MMM_PIO2_LO);
   return x < 0 ? -r : r;
 }
+MMM_FN double mmm_asin(double x) { double w; return mmm_asin_w(x, &w); }
+/* sin / cos of the steering limit pi/3 (the double 0x1.0c152382d7365p+0), correctly rounded */
+#define MMM_SIN_PI3 0x1.bb67ae8584caap-1
+#define MMM_COS_PI3 0x1.0000000000001p-1
 /* exp: x = k ln2 + r, |r| <= ln2/2, Taylor to r^14, exact scaling */
 MMM_FN double mmm_exp(double x) {
   if (x < -1000.0) return 0.0;

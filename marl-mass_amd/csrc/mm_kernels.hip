@@ -200,7 +200,8 @@ MM_DEV void store_veh(const DevState &st, long long i, const Veh &v, bool with_s
 // safe_controller.py:84-98 MDPLCVehicle.steering_control in "steer_vel" mode: a steering VELOCITY that
 // tracks the scaled-down reference angle (KP_STEER 20, STEER_TARGET_RF 0.125)
 MM_DEV double steer_vel_command(double steering_ref, double sang) { return 20 * (steering_ref * 0.125 - sang); }
-MM_DEV void controlled_act(Veh &v, int action, bool sv = false) {
+// st_s / st_c: sin / cos of the steering command (see steering_control; st_c == 0: not known)
+MM_DEV void controlled_act(Veh &v, int action, bool sv, double &st_s, double &st_c) {
   if (lane_after_end(v.tlane, v.x)) v.tlane = next_lane(v.tlane, v.x, v.y);  // follow_road :136-144
   if (action == 2 || action == 0) {
     // only road (b,c) has two lanes; elsewhere the clipped candidate is the lane itself
@@ -208,8 +209,8 @@ MM_DEV void controlled_act(Veh &v, int action, bool sv = false) {
     if (lane_road(v.tlane) == 1) cand = (action == 2) ? MM_LANE_BC1 : MM_LANE_BC0;
     if (lane_reachable(cand, v.x, v.y)) v.tlane = cand;
   }
-  double steer = steering_control(v.x, v.y, v.h, v.v, v.tlane);
-  if (sv) steer = steer_vel_command(steer, v.sang);
+  double steer = steering_control(v.x, v.y, v.h, v.v, v.tlane, st_s, st_c);
+  if (sv) { steer = steer_vel_command(steer, v.sang); st_c = 0; }
   v.act_acc = (1 / kTauA) * (v.tspeed - v.v);  // speed_control :189-197
   v.act_steer = clipd(steer, -kPi / 3, kPi / 3);
 }
@@ -235,8 +236,8 @@ MM_DEV void hl_act(Veh &v, int action) {
 }
 
 // kinematics.py:143-152 clip_actions (+ safe_controller.py:100-104)
-MM_DEV void clip_actions(Veh &v, bool lc_vehicle) {
-  if (v.crashed) { v.act_steer = 0; v.act_acc = -1.0 * v.v; }
+MM_DEV void clip_actions(Veh &v, bool lc_vehicle, double &st_s, double &st_c) {
+  if (v.crashed) { v.act_steer = 0; st_s = 0; st_c = 1; v.act_acc = -1.0 * v.v; }
   if (v.v > kMaxSpeed) v.act_acc = fmin(v.act_acc, 1.0 * (kMaxSpeed - v.v));
   else if (v.v < -kMaxSpeed) v.act_acc = fmax(v.act_acc, 1.0 * (kMaxSpeed - v.v));
   if (lc_vehicle) v.act_acc = clipd(v.act_acc, kLcMinAcc, kLcMaxAcc);  // MDPLCVehicle only
@@ -274,12 +275,18 @@ struct Cand {
 // sin(beta), cos(psi' + beta), cos(psi') and the three corner angles -- become ONE sincos of the steering angle and ONE of
 // the new heading plus angle sums; beta itself is never formed (include/mm_math.h, "angle-sum forms").
 template <int KIND, bool SHIELDED, bool CORNERS = SHIELDED>
-MM_DEV Cand predict(const Veh &v, double steer, double sh, double ch, double dt, bool sv = false) {
+MM_DEV Cand predict(const Veh &v, double steer, double st_s, double st_c, double sh, double ch, double dt, bool sv = false) {
   Cand c;
   // "steer_vel" (safe_controller.py:124-150): the slip angle comes from the steering-angle STATE and the
   // heading advances by d_heading without the dt factor (sic, :135)
-  double ss, cs, sb, cb;
-  mmm_sincos(sv ? v.sang : steer, &ss, &cs);
+  // st_s / st_c: sin / cos of `steer` as steering_control left them (st_c == 0: unknown -- a persisting IDM action, an
+  // angle handed in through mm_shield_actions, steer_vel -- and the general sincos runs)
+  double ss = st_s, cs = st_c, sb, cb;
+  if (__any(sv || st_c == 0.0)) {
+    double s2, c2;
+    mmm_sincos(sv ? v.sang : steer, &s2, &c2);
+    if (sv || st_c == 0.0) { ss = s2; cs = c2; }
+  }
   mmm_slip_sincos(1.0 / 2 * (ss / cs), &sb, &cb);  // beta = atan(1/2 tan(delta)): its sin and cos
   double vx = v.v * mmm_cos_sum(sh, ch, sb, cb), vy = v.v * mmm_sin_sum(sh, ch, sb, cb);
   c.x = v.x + vx * dt;
@@ -868,6 +875,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
 
   // derived per-vehicle registers the shield keeps current across sub-steps
   double cpsi = 1.0, spsi = 0.0;  // cos / sin of my current heading (every kernel: the bicycle step is built on them)
+  double st_s = 0.0, st_c = 0.0;  // sin / cos of v.act_steer once steering_control has produced it (st_c == 0: not known -- an IDM action persisting from the last launch -- and predict() runs the general sincos)
   if (v.present) mmm_sincos(v.h, &spsi, &cpsi);
   int pk_self = v.lane;  // pose code of my current (pre-step) pose
   if (SHIELDED && v.present) pk_self = pose_code(v.lane, next_lane(v.lane, v.x, v.y), MASS ? corner_flags(v.x, v.y, spsi, cpsi, v.lane) : 0);
@@ -916,7 +924,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
       if (time % c.nsub == 0) hl_act<KIND>(v, action);  // action_type.act abstract.py:516-519
     }
     const int tl_pre = v.tlane;  // what an HDV acting before this vehicle still sees
-    if (live && !hdv) controlled_act(v, -1, sv);  // road.act road.py:269-278
+    if (live && !hdv) controlled_act(v, -1, sv, st_s, st_c);  // road.act road.py:269-278
     s_cold[C_TSPEED][tid] = v.tspeed;
     if constexpr (MIXED) {
       // ---------------- IDMVehicle.act for the HDVs (behavior.py:74-100) -------------------------
@@ -997,19 +1005,19 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         }
         if (acting) {
           v.tlane = tl_post;
-          v.act_steer = clipd(steering_control(v.x, v.y, v.h, v.v, v.tlane), -kPi / 3, kPi / 3);
+          v.act_steer = clipd(steering_control(v.x, v.y, v.h, v.v, v.tlane, st_s, st_c), -kPi / 3, kPi / 3);
           v.act_acc = clipd(idm_acceleration(self, front0), -6.0, 6.0);
         }
       }
       if (hdv && live) v.gvx += dt;  // IDMVehicle.step: self.timer += dt (behavior.py:102-109)
     }
-    if (live) clip_actions(v, LC && !hdv);
+    if (live) clip_actions(v, LC && !hdv, st_s, st_c);
     STAMP(1);  // act
     // predicted post-state for the nominal steering (the only one when nothing vetoes)
     Cand cA;
     memset(&cA, 0, sizeof cA);
     const bool shield_on = SHIELDED && live && !hdv && v.hist_len >= 2;  // gate safe_controller.py:232-239
-    if (live) cA = predict<KIND, SHIELDED, MASS>(v, v.act_steer, spsi, cpsi, dt, sv && !hdv);
+    if (live) cA = predict<KIND, SHIELDED, MASS>(v, v.act_steer, st_s, st_c, spsi, cpsi, dt, sv && !hdv);
     auto park = [&](auto base_c, const Cand &cc, double steer) {  // a candidate's LDS image (shielded kernels only)
       constexpr int base = decltype(base_c)::value;
       if constexpr (SHIELDED) {
@@ -1030,9 +1038,10 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     auto make_B = [&]() {
       if constexpr (SHIELDED) {
         if (needB && !haveB) {
-          double steerB = steering_control(v.x, v.y, v.h, v.v, v.lane);
+          double sB, cB;
+          double steerB = steering_control(v.x, v.y, v.h, v.v, v.lane, sB, cB);
           if (sv) steerB = steer_vel_command(steerB, v.sang);
-          park(std::integral_constant<int, C_B>{}, predict<KIND, true, MASS>(v, steerB, spsi, CPSI(), dt, sv), steerB);
+          park(std::integral_constant<int, C_B>{}, predict<KIND, true, MASS>(v, steerB, sB, cB, spsi, CPSI(), dt, sv), steerB);
           haveB = true;
         }
       }

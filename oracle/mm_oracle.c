@@ -86,6 +86,9 @@ static const int LANE_FORBIDDEN[6] = {0, 0, 1, 0, 1, 1};
 typedef struct {
   double x, y, heading, speed, target_speed;
   double act_steer, act_acc;   /* self.action */
+  /* math mode 1 only: sin / cos of the last steering_control result, as the device carries them into the bicycle step
+   * (valid while act_steer / the veto steering still IS that result; see vehicle_step) */
+  double sc_steer, sc_sin, sc_cos; int sc_valid;
   double safe_steer, safe_acc; /* self.safe_action */
   double g_vx;                 /* fg_params["g"]["vx"] */
   double h1[2], h2[2];         /* state_hist[-1], [-2]: x, vx (all the shield reads of a record) */
@@ -269,7 +272,7 @@ static void follow_road(Veh *v) {
     v->target_lane = next_lane(v->target_lane, v->x, v->y);
 }
 /* controller.py:146-187 steering_control */
-static double steering_control(const Veh *v, int target_lane) {
+static double steering_control(Veh *v, int target_lane) {
   const double KP_HEADING = 1 / TAU_DS, KP_LATERAL = 1.0 / 3 * KP_HEADING;
   const double PURSUIT_TAU = 0.5 * TAU_DS, MAX_STEER = PI / 3;
   double s, r;
@@ -280,13 +283,24 @@ static double steering_control(const Veh *v, int target_lane) {
   double heading_command = m_asin(clipd(lateral_speed_command / not_zero(v->speed), -1, 1));
   double heading_ref = lane_future_heading + clipd(heading_command, -PI / 4, PI / 4);
   double heading_rate_command = KP_HEADING * wrap_to_pi(heading_ref - v->heading);
+  if (g_math_mode) { /* device arithmetic: the command is an arcsine, so its sin is the argument and its cos the square root asin forms */
+    const double arg = clipd(VEH_LENGTH / 2 / not_zero(v->speed) * heading_rate_command, -1, 1);
+    double w;
+    const double steer = mmm_asin_w(arg, &w);
+    const int sat = fabs(steer) > MAX_STEER;
+    v->sc_sin = sat ? (arg < 0 ? -MMM_SIN_PI3 : MMM_SIN_PI3) : arg;
+    v->sc_cos = sat ? MMM_COS_PI3 : w;
+    v->sc_steer = clipd(steer, -MAX_STEER, MAX_STEER);
+    v->sc_valid = 1;
+    return v->sc_steer;
+  }
   double steering_angle =
       m_asin(clipd(VEH_LENGTH / 2 / not_zero(v->speed) * heading_rate_command, -1, 1));
   return clipd(steering_angle, -MAX_STEER, MAX_STEER);
 }
 /* safe_controller.py:84-98 MDPLCVehicle.steering_control: in "steer_vel" mode the command is a
  * steering VELOCITY tracking a scaled-down reference angle (KP_STEER 20, STEER_TARGET_RF 0.125) */
-static double lc_steering_control(const Veh *v, int target_lane) {
+static double lc_steering_control(Veh *v, int target_lane) {
   double steering_ref = steering_control(v, target_lane);
   if (v->steer_vel) {
     steering_ref = steering_ref * 0.125;
@@ -927,7 +941,8 @@ static int vehicle_step(const MMConfig *cfg, Env *e, int i, double dt) {
      * of the steering angle and one of the new heading (include/mm_math.h, "angle-sum forms"); beta itself is never formed */
     const int sv = is_lc && v->steer_vel;
     double ss, cs, sb, cb, sh, ch;
-    mmm_sincos(sv ? v->steer_angle : steer, &ss, &cs);
+    if (!sv && v->sc_valid && steer == v->sc_steer) { ss = v->sc_sin; cs = v->sc_cos; } /* steer IS the last steering_control result */
+    else mmm_sincos(sv ? v->steer_angle : steer, &ss, &cs); /* crashed (0 -> (0, 1)), a persisting IDM action, steer_vel */
     mmm_slip_sincos(1.0 / 2 * (ss / cs), &sb, &cb);
     mmm_sincos(v->heading, &sh, &ch);
     double vx = v->speed * mmm_cos_sum(sh, ch, sb, cb);
@@ -1261,6 +1276,7 @@ static void init_vehicle(Veh *v) {
     v->target_speed = index_to_speed(v->speed_index);
   }
   v->act_steer = v->act_acc = 0;
+  v->sc_valid = 0;
   v->safe_steer = v->safe_acc = 0;
   v->g_vx = NAN; /* fg_params = None */
   v->steer_angle = 0; /* safe_controller.py:54 */
@@ -1350,6 +1366,7 @@ static void load_env(const struct MMHandle_ *h, int64_t e_idx, Env *e) {
     if (v->kind == 2) { /* HDV: the SAFE_* planes persist its last IDM action, G_VX its MOBIL timer */
       v->act_steer = v->safe_steer; v->act_acc = v->safe_acc; v->timer = v->g_vx;
     }
+    v->sc_valid = 0;
   }
   e->steps = I[MM_E_STEPS * h->E + e_idx]; e->time = I[MM_E_TIME * h->E + e_idx];
   e->n_merge = I[MM_E_N_MERGE * h->E + e_idx]; e->episode = I[MM_E_EPISODE * h->E + e_idx];
