@@ -76,6 +76,28 @@ def cpu_baseline(args, env_id, cfg, kw):
     return out
 
 
+def fidelity_mode_rate(args, dev, E, N, cfg, kw, ring, steps=12):
+    """The headline workload once more with qp_solver="ipm" (every QP through the interior-point iteration the
+    reference's cvxopt call runs, bit-identical to the reference-side restatement): same stationary batch, a short
+    timed window -- it is ~20x slower than the exact mode and only reported."""
+    from marl_mass_amd import VecMergeEnv, _cabi as abi
+    env = VecMergeEnv(E, N, env_id=args.env_id, config=cfg, device=dev, **dict(kw, qp_solver="ipm"))
+    env.reset()
+    ge = torch.arange(0, E, dtype=torch.int64, device=dev)
+    env.env_i32[abi.EP["STEPS"]] = ((ge * 37) % env.T).to(torch.int32)
+    for t in range(env.T + 2):
+        env.step(ring[t % 16])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(steps):
+        env.step(ring[t % 16])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"qp_solver": "ipm", "value": E * N * steps / dt, "unit": "agent-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "note": "same workload, shield QP by cvxopt's interior-point algorithm (include/mm_qp.h), one QP per lane; "
+                    "the exact mode above returns the true minimiser of the same QP (DESIGN.md 3 quantifies the difference)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +118,7 @@ def main():
     ap.add_argument("--obs-f64", action="store_true")
     ap.add_argument("--hdv", type=int, default=0, help="mixed traffic: the last HDV of the --agents vehicles are IDM/MOBIL HDVs (not the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fidelity-line", action="store_true", help="skip the short qp_solver=ipm measurement appended to the headline line")
     ap.add_argument("--cpu-envs", type=int, default=32768)
     ap.add_argument("--cpu-steps", type=int, default=400)
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -252,6 +275,10 @@ def main():
             line["rehearsal"] = "all %d ranks on cuda:0, gloo collectives: NOT a scaling measurement" % world
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(args, args.env_id, cfg, kw)
+        if headline and world == 1 and not args.no_fidelity_line:
+            # the same workload with the shield's QP through cvxopt's interior-point iteration: reported
+            # beside the headline, never as `value`
+            line["qp_fidelity_mode"] = fidelity_mode_rate(args, dev, E, N, cfg, kw, ring)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
