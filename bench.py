@@ -43,6 +43,16 @@ def algorithmic_bytes_per_agent_step(env_id, N):
     return 2 * S + 4 * n_s + 21 + 41.0 / N
 
 
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, env_id, cfg, kw):
     """Times the CPU oracle (the C restatement, `kind: port`) on a bounded sample of the workload."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
@@ -60,7 +70,21 @@ def cpu_baseline(args, env_id, cfg, kw):
         env.step(acts[t % 8])
     dt = time.perf_counter() - t0
     out = {"value": E * N * K / dt, "unit": "agent-steps/s", "cores": int(threads), "kind": "port",
-           "sample": "%d envs x %d CAVs x %d steps, same config, OpenMP over envs (%.1f s)" % (E, N, K, dt)}
+           "sample": "%d envs x %d CAVs x %d steps, same config, OpenMP over envs (%.1f s)" % (E, N, K, dt),
+           "host": {"cpu_model": _cpu_model(), "logical_cpus": os.cpu_count()}}
+    # the same port on ONE thread (SURVEY 8d asks for both): a smaller sample of the same workload
+    oracle_env.library().lib.orc_set_threads(1)
+    E1, K1 = max(E // 16, 64), max(K // 4, 20)
+    env1 = oracle_env.OracleEnv(E1, N, env_id=env_id, config=cfg, **kw)
+    env1.reset()
+    env1.step(acts[0][:E1].contiguous())
+    t0 = time.perf_counter()
+    for t in range(K1):
+        env1.step(acts[t % 8][:E1].contiguous())
+    dt1 = time.perf_counter() - t0
+    out["single_thread"] = {"value": E1 * N * K1 / dt1, "unit": "agent-steps/s", "cores": 1,
+                            "sample": "%d envs x %d CAVs x %d steps (%.1f s)" % (E1, N, K1, dt1)}
+    oracle_env.library().lib.orc_set_threads(int(threads))
     # the reference's OWN Python path cannot travel to this box; its timing is regenerated in the build container by
     # tools/time_reference.py and committed as profiles/reference_cpu.json (host, cores and stand-in caveats inside)
     try:
