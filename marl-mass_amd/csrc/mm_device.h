@@ -159,9 +159,10 @@ MM_DEV int speed_to_index(double speed) {  // controller.py:327-337, np.round = 
 }
 MM_DEV double index_to_speed(int i) { return 10 + i * (30.0 - 10) / (5 - 1); }  // :313-325
 
-// ss / cs: sin and cos of the returned (clipped) angle.  The command is an arcsine, so they are its argument and the
-// square root asin already formed -- or the constants at the +-pi/3 limit (device arithmetic, oracle math mode 1 alike)
-MM_DEV double steering_control(double x, double y, double heading, double speed, int tl, double &ss, double &cs) {  // :146-187
+// half_tan: 1/2 tan of the returned (clipped) angle -- what the bicycle step needs of it (beta = atan(1/2 tan delta)).  The
+// command is an arcsine, so sin / cos of it are its argument and the square root asin already formed (or the constants at
+// the +-pi/3 limit): no second range reduction, no polynomials (device arithmetic, oracle math mode 1 alike)
+MM_DEV double steering_control(double x, double y, double heading, double speed, int tl, double &half_tan) {  // :146-187
   constexpr double KP_HEADING = 1 / kTauDs, KP_LATERAL = 1.0 / 3 * KP_HEADING, PURSUIT_TAU = 0.5 * kTauDs;
   double s, r;
   lane_local(tl, x, y, s, r);
@@ -176,13 +177,14 @@ MM_DEV double steering_control(double x, double y, double heading, double speed,
   double w;
   const double steer = mmm_asin_w(arg, &w);
   const bool sat = fabs(steer) > kPi / 3;
-  ss = sat ? (arg < 0 ? -MMM_SIN_PI3 : MMM_SIN_PI3) : arg;
-  cs = sat ? MMM_COS_PI3 : w;
+  const double ss = sat ? (arg < 0 ? -MMM_SIN_PI3 : MMM_SIN_PI3) : arg;
+  const double cs = sat ? MMM_COS_PI3 : w;
+  half_tan = 1.0 / 2 * (ss / cs);
   return clipd(steer, -kPi / 3, kPi / 3);
 }
 MM_DEV double steering_control(double x, double y, double heading, double speed, int tl) {
-  double ss, cs;
-  return steering_control(x, y, heading, speed, tl, ss, cs);
+  double ht;
+  return steering_control(x, y, heading, speed, tl, ht);
 }
 
 // ---- utils.py rotated-rectangle intersection (:55-121), +angle rotation quirk kept ------------

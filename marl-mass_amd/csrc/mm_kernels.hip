@@ -200,8 +200,8 @@ MM_DEV void store_veh(const DevState &st, long long i, const Veh &v, bool with_s
 // safe_controller.py:84-98 MDPLCVehicle.steering_control in "steer_vel" mode: a steering VELOCITY that
 // tracks the scaled-down reference angle (KP_STEER 20, STEER_TARGET_RF 0.125)
 MM_DEV double steer_vel_command(double steering_ref, double sang) { return 20 * (steering_ref * 0.125 - sang); }
-// st_s / st_c: sin / cos of the steering command (see steering_control; st_c == 0: not known)
-MM_DEV void controlled_act(Veh &v, int action, bool sv, double &st_s, double &st_c) {
+// st_t: 1/2 tan of the steering command (see steering_control; NaN: not known)
+MM_DEV void controlled_act(Veh &v, int action, bool sv, double &st_t) {
   if (lane_after_end(v.tlane, v.x)) v.tlane = next_lane(v.tlane, v.x, v.y);  // follow_road :136-144
   if (action == 2 || action == 0) {
     // only road (b,c) has two lanes; elsewhere the clipped candidate is the lane itself
@@ -209,8 +209,8 @@ MM_DEV void controlled_act(Veh &v, int action, bool sv, double &st_s, double &st
     if (lane_road(v.tlane) == 1) cand = (action == 2) ? MM_LANE_BC1 : MM_LANE_BC0;
     if (lane_reachable(cand, v.x, v.y)) v.tlane = cand;
   }
-  double steer = steering_control(v.x, v.y, v.h, v.v, v.tlane, st_s, st_c);
-  if (sv) { steer = steer_vel_command(steer, v.sang); st_c = 0; }
+  double steer = steering_control(v.x, v.y, v.h, v.v, v.tlane, st_t);
+  if (sv) { steer = steer_vel_command(steer, v.sang); st_t = __builtin_nan(""); }
   v.act_acc = (1 / kTauA) * (v.tspeed - v.v);  // speed_control :189-197
   v.act_steer = clipd(steer, -kPi / 3, kPi / 3);
 }
@@ -236,8 +236,8 @@ MM_DEV void hl_act(Veh &v, int action) {
 }
 
 // kinematics.py:143-152 clip_actions (+ safe_controller.py:100-104)
-MM_DEV void clip_actions(Veh &v, bool lc_vehicle, double &st_s, double &st_c) {
-  if (v.crashed) { v.act_steer = 0; st_s = 0; st_c = 1; v.act_acc = -1.0 * v.v; }
+MM_DEV void clip_actions(Veh &v, bool lc_vehicle, double &st_t) {
+  if (v.crashed) { v.act_steer = 0; st_t = 0; v.act_acc = -1.0 * v.v; }
   if (v.v > kMaxSpeed) v.act_acc = fmin(v.act_acc, 1.0 * (kMaxSpeed - v.v));
   else if (v.v < -kMaxSpeed) v.act_acc = fmax(v.act_acc, 1.0 * (kMaxSpeed - v.v));
   if (lc_vehicle) v.act_acc = clipd(v.act_acc, kLcMinAcc, kLcMaxAcc);  // MDPLCVehicle only
@@ -274,20 +274,23 @@ struct Cand {
 // heading carried along (sh, ch), the reference's eleven trigonometric calls -- arctan(1/2 tan delta), cos / sin(psi + beta),
 // sin(beta), cos(psi' + beta), cos(psi') and the three corner angles -- become ONE sincos of the steering angle and ONE of
 // the new heading plus angle sums; beta itself is never formed (include/mm_math.h, "angle-sum forms").
-template <int KIND, bool SHIELDED, bool CORNERS = SHIELDED>
-MM_DEV Cand predict(const Veh &v, double steer, double st_s, double st_c, double sh, double ch, double dt, bool sv = false) {
+// GENERAL: the instantiation can meet a steering angle that did not come out of steering_control (kernels with HDVs / steer_vel)
+template <int KIND, bool SHIELDED, bool CORNERS = SHIELDED, bool GENERAL = true>
+MM_DEV Cand predict(const Veh &v, double steer, double st_t, double sh, double ch, double dt, bool sv = false) {
   Cand c;
   // "steer_vel" (safe_controller.py:124-150): the slip angle comes from the steering-angle STATE and the
   // heading advances by d_heading without the dt factor (sic, :135)
-  // st_s / st_c: sin / cos of `steer` as steering_control left them (st_c == 0: unknown -- a persisting IDM action, an
-  // angle handed in through mm_shield_actions, steer_vel -- and the general sincos runs)
-  double ss = st_s, cs = st_c, sb, cb;
-  if (__any(sv || st_c == 0.0)) {
-    double s2, c2;
-    mmm_sincos(sv ? v.sang : steer, &s2, &c2);
-    if (sv || st_c == 0.0) { ss = s2; cs = c2; }
+  // st_t: 1/2 tan(steer) as steering_control left it (NaN: unknown -- a persisting IDM action, steer_vel -- and the
+  // general sincos runs)
+  double ht = st_t, sb, cb;
+  if constexpr (GENERAL) {
+    if (__any(sv || st_t != st_t)) {
+      double s2, c2;
+      mmm_sincos(sv ? v.sang : steer, &s2, &c2);
+      if (sv || st_t != st_t) ht = 1.0 / 2 * (s2 / c2);
+    }
   }
-  mmm_slip_sincos(1.0 / 2 * (ss / cs), &sb, &cb);  // beta = atan(1/2 tan(delta)): its sin and cos
+  mmm_slip_sincos(ht, &sb, &cb);  // beta = atan(1/2 tan(delta)): its sin and cos
   double vx = v.v * mmm_cos_sum(sh, ch, sb, cb), vy = v.v * mmm_sin_sum(sh, ch, sb, cb);
   c.x = v.x + vx * dt;
   c.y = v.y + vy * dt;
@@ -816,7 +819,9 @@ template <int G, int SHIELD, bool MIXED>
 constexpr int step_min_waves() { return SHIELD == MM_SHIELD_NONE ? (MIXED ? MM_GENERAL_NONE_WAVES : MM_NONE_WAVES) : MM_MIN_WAVES; }
 // IPM: the MM_QP_IPM fidelity mode (the shield's QP by cvxopt's interior-point algorithm, include/mm_qp.h); carried by
 // general (MIXED) instantiations only, which run the literal sweep -- one QP per vehicle per sub-step, as the reference
-template <int G, int KIND, int SHIELD, bool MIXED, bool IPM = false>
+// TRACE: the per-sub-step trace planes (MMStepOut.trace, tests / profile export) are a compile-time property: the
+// production instantiation carries neither the stores nor the eight QP-trace registers per lane
+template <int G, int KIND, int SHIELD, bool MIXED, bool IPM = false, bool TRACE = false>
 #ifndef MM_STEP_BLOCK
 #define MM_STEP_BLOCK 64  // one wave per workgroup: waves of a 256-thread block drifted ~12 % apart and the block held its LDS until the slowest was done (0.355 -> 0.333 ms)
 #endif
@@ -875,7 +880,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
 
   // derived per-vehicle registers the shield keeps current across sub-steps
   double cpsi = 1.0, spsi = 0.0;  // cos / sin of my current heading (every kernel: the bicycle step is built on them)
-  double st_s = 0.0, st_c = 0.0;  // sin / cos of v.act_steer once steering_control has produced it (st_c == 0: not known -- an IDM action persisting from the last launch -- and predict() runs the general sincos)
+  double st_t = __builtin_nan("");  // 1/2 tan(v.act_steer) once steering_control has produced it (NaN: not known -- an IDM action persisting from the last launch -- and predict() runs the general sincos)
   if (v.present) mmm_sincos(v.h, &spsi, &cpsi);
   int pk_self = v.lane;  // pose code of my current (pre-step) pose
   if (SHIELDED && v.present) pk_self = pose_code(v.lane, next_lane(v.lane, v.x, v.y), MASS ? corner_flags(v.x, v.y, spsi, cpsi, v.lane) : 0);
@@ -924,7 +929,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
       if (time % c.nsub == 0) hl_act<KIND>(v, action);  // action_type.act abstract.py:516-519
     }
     const int tl_pre = v.tlane;  // what an HDV acting before this vehicle still sees
-    if (live && !hdv) controlled_act(v, -1, sv, st_s, st_c);  // road.act road.py:269-278
+    if (live && !hdv) controlled_act(v, -1, sv, st_t);  // road.act road.py:269-278
     s_cold[C_TSPEED][tid] = v.tspeed;
     if constexpr (MIXED) {
       // ---------------- IDMVehicle.act for the HDVs (behavior.py:74-100) -------------------------
@@ -1005,19 +1010,19 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         }
         if (acting) {
           v.tlane = tl_post;
-          v.act_steer = clipd(steering_control(v.x, v.y, v.h, v.v, v.tlane, st_s, st_c), -kPi / 3, kPi / 3);
+          v.act_steer = clipd(steering_control(v.x, v.y, v.h, v.v, v.tlane, st_t), -kPi / 3, kPi / 3);
           v.act_acc = clipd(idm_acceleration(self, front0), -6.0, 6.0);
         }
       }
       if (hdv && live) v.gvx += dt;  // IDMVehicle.step: self.timer += dt (behavior.py:102-109)
     }
-    if (live) clip_actions(v, LC && !hdv, st_s, st_c);
+    if (live) clip_actions(v, LC && !hdv, st_t);
     STAMP(1);  // act
     // predicted post-state for the nominal steering (the only one when nothing vetoes)
     Cand cA;
     memset(&cA, 0, sizeof cA);
     const bool shield_on = SHIELDED && live && !hdv && v.hist_len >= 2;  // gate safe_controller.py:232-239
-    if (live) cA = predict<KIND, SHIELDED, MASS>(v, v.act_steer, st_s, st_c, spsi, cpsi, dt, sv && !hdv);
+    if (live) cA = predict<KIND, SHIELDED, MASS, MIXED>(v, v.act_steer, st_t, spsi, cpsi, dt, sv && !hdv);
     auto park = [&](auto base_c, const Cand &cc, double steer) {  // a candidate's LDS image (shielded kernels only)
       constexpr int base = decltype(base_c)::value;
       if constexpr (SHIELDED) {
@@ -1038,10 +1043,10 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     auto make_B = [&]() {
       if constexpr (SHIELDED) {
         if (needB && !haveB) {
-          double sB, cB;
-          double steerB = steering_control(v.x, v.y, v.h, v.v, v.lane, sB, cB);
+          double tB;
+          double steerB = steering_control(v.x, v.y, v.h, v.v, v.lane, tB);
           if (sv) steerB = steer_vel_command(steerB, v.sang);
-          park(std::integral_constant<int, C_B>{}, predict<KIND, true, MASS>(v, steerB, sB, cB, spsi, CPSI(), dt, sv), steerB);
+          park(std::integral_constant<int, C_B>{}, predict<KIND, true, MASS, MIXED>(v, steerB, tB, spsi, CPSI(), dt, sv), steerB);
           haveB = true;
         }
       }
@@ -1183,7 +1188,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
             acc_cur = acc_next;
             if (!MASS || !__any(changed)) break;
           }
-          if (out.trace && shield_on) trace_status(out.trace + (long long)k * MM_T_COUNT * A + i, A, so);
+          if (TRACE && shield_on) trace_status(out.trace + (long long)k * MM_T_COUNT * A + i, A, so);
           STAMP(4);  // selection + fixed-point rounds
           const bool want_B = shield_on && so.veto && needB;
           if (want_B) make_B();
@@ -1289,7 +1294,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           if (IPM && mine && s1.bounds) atomicOr(c.err, MM_LATCH_QP_BOUNDS);
           if (mine) {
             new_acc = s1.acc; veto = s1.veto; new_flags = s1.flags; qt = s1.qt;
-            if (out.trace) trace_status(out.trace + (long long)k * MM_T_COUNT * A + i, A, s1);
+            if (TRACE) trace_status(out.trace + (long long)k * MM_T_COUNT * A + i, A, s1);
             use_B = veto && needB;
             const Cand cc = chosen(use_B);
             double nv = v.v + new_acc * dt;
@@ -1306,7 +1311,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
      }
     }
     STAMP(6);  // serial fallback (if taken) + sweep exit
-    if (SHIELDED && out.trace && live) {  // QP internals go out now so they need not stay in registers
+    if (SHIELDED && TRACE && live) {  // QP internals go out now so they need not stay in registers
       double *t = out.trace + (long long)k * MM_T_COUNT * A + i;
       t[MM_T_QP_ROWS * A] = qt.rows; t[MM_T_QP_A * A] = qt.a;
       t[MM_T_QP_H0 * A] = qt.h0; t[MM_T_QP_H1 * A] = qt.h1; t[MM_T_QP_H2 * A] = qt.h2;
@@ -1404,7 +1409,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
     }
     STAMP(8);  // collisions
     if (env_active) time += 1;
-    if (out.trace && live) {
+    if (TRACE && live) {
       double *t = out.trace + (long long)k * MM_T_COUNT * A + i;
       t[MM_T_X * A] = v.x; t[MM_T_Y * A] = v.y; t[MM_T_HEADING * A] = v.h; t[MM_T_SPEED * A] = v.v;
       double steer_tr = v.act_steer;
@@ -2067,8 +2072,12 @@ template <int G, int KIND, int SHIELD, bool MIXED, bool IPM = false>
 static void launch_step_t(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   const long long threads = (long long)h->E * G;
   const unsigned grid = (unsigned)((threads + MM_STEP_BLOCK - 1) / MM_STEP_BLOCK);
-  hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, MIXED, IPM>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dev_cfg(h), dev_state(h),
-                     actions, *out, h->metrics ? h->metrics_partial : nullptr);
+  if (out->trace)
+    hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, MIXED, IPM, true>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dev_cfg(h), dev_state(h),
+                       actions, *out, h->metrics ? h->metrics_partial : nullptr);
+  else
+    hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, MIXED, IPM, false>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dev_cfg(h), dev_state(h),
+                       actions, *out, h->metrics ? h->metrics_partial : nullptr);
 }
 template <int G, bool MIXED>
 static void launch_step_m(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 C="$1"; shift
 O=$R/gpurun_out/pmc_once; rm -rf "$O"; mkdir -p "$O"
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --pmc $C --output-format csv -d "$O" -o pmc -- python3 "$R/bench.py" --no-cpu-baseline --steps 20 --warmup 5 "$@" > /dev/null 2> "$O/err.txt" || { tail -5 "$O/err.txt"; exit 1; }
+rocprofv3 --pmc $C --output-format csv -d "$O" -o pmc -- python3 "$R/bench.py" --no-cpu-baseline --no-fidelity-line --steps 20 --warmup 5 "$@" > /dev/null 2> "$O/err.txt" || { tail -5 "$O/err.txt"; exit 1; }
 python3 - "$O" <<'PY'
 import csv, glob, sys, os
 acc = {}
