@@ -411,100 +411,118 @@ template <int G, int KIND, bool LEND = false>
 MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, bool valid, void *obs,
                     uint8_t *avail, float *stage = nullptr, const double *sincos_h = nullptr) {
   constexpr int F = (KIND == MM_ENV_V1) ? 6 : 5;
+  constexpr int S = 5 * F;
   const bool ctrl = v.present && v.kind != 2;  // only controlled vehicles observe / have an action mask
-  double sps, cps;
-  if (sincos_h) { sps = sincos_h[0]; cps = sincos_h[1]; }  // the step kernel carries sin / cos of the heading along
-  else mmm_sincos(v.h, &sps, &cps);
-  const double vx = v.v * cps, vy = v.v * sps;  // Vehicle.velocity kinematics.py:215-217
-  const double sx = lane_sx(v.lane);
-  // pass 1: sort keys of close_vehicles_to (road.py:257-267): |lane_distance_to|, inf if not within 180 m
-  double key[G];
-  key[0] = 0;
-  for_partners<G>([&](auto mc) {
-    constexpr int m = decltype(mc)::value;
-    double px = dppx_d<m>(v.x), py = dppx_d<m>(v.y);
-    bool pp = dppx_i<m>((int)v.present) != 0;
-    double dx = px - v.x, dy = py - v.y;
-    bool close = pp && (dx * dx + dy * dy) < kT180;  // norm < PERCEPTION_DISTANCE, sqrt-free
-    key[m] = close ? fabs((px - sx) - (v.x - sx)) : INFINITY;
-  });
-  double row[4][F - 1];
-  bool have[4] = {false, false, false, false};
-#pragma unroll
-  for (int q = 0; q < 4; q++)
-#pragma unroll
-    for (int f = 0; f < F - 1; f++) row[q][f] = 0;
-  // pass 2: the 4 nearest in stable order become rows 1..4
-  for_partners<G>([&](auto mc) {
-    constexpr int m = decltype(mc)::value;
-    int rank = 0;
-#pragma unroll
-    for (int m2 = 1; m2 < G; m2++)
-      if (m2 != m) rank += (key[m2] < key[m] || (key[m2] == key[m] && (a ^ m2) < (a ^ m))) ? 1 : 0;
-    double px = dppx_d<m>(v.x), py = dppx_d<m>(v.y), pvx = dppx_d<m>(vx), pvy = dppx_d<m>(vy);
-    double ph = (KIND == MM_ENV_V1) ? dppx_d<m>(v.h) : 0.0;
-    if (KIND == MM_ENV_V1 && c.steer_vel) {  // MDPLCVehicle.to_dict under "steer_vel" (safe_controller.py:75-81):
-      const int pkind = dppx_i<m>(v.kind);   // a CAV neighbour's heading is relative to the observer's
-      if (pkind == 1) ph = ph - v.h;
-    }
-    bool use = key[m] < INFINITY;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      if (use && rank == q) {
-        have[q] = true;
-        row[q][0] = px - v.x; row[q][1] = py - v.y; row[q][2] = pvx - vx; row[q][3] = pvy - vy;
-        if (KIND == MM_ENV_V1) row[q][F - 2] = ph;
-      }
-    }
-  });
-  // normalize_obs :181-193 via utils.lmap :16-18 (no clip); ranges :171-176, :238-239
-  const double lo[5] = {-5.0 * 30, -12, -1.5 * 30, -1.5 * 30, -kPi / 2};
-  const double span[5] = {300.0, 24.0, 90.0, 90.0, kPi / 2 - (-kPi / 2)};  // x[1] - x[0] of lmap
-  const double ispan[5] = {1.0 / 300.0, 1.0 / 24.0, 1.0 / 90.0, 1.0 / 90.0, 1.0 / (kPi / 2 - (-kPi / 2))};
-  auto lmap = [&](double val, int f) { return -1 + div_c((val - lo[f]) * (1 - (-1)), span[f], ispan[f]); };
-  const double ego[5] = {v.x, v.y, vx, vy, v.h};
-  auto emit = [&](auto put) {
-    put(0, ctrl ? 1.0 : 0.0);
-#pragma unroll
-    for (int f = 0; f < F - 1; f++) put(1 + f, ctrl ? lmap(ego[f], f) : 0.0);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const bool hq = ctrl && have[q];
-      put((q + 1) * F, hq ? 1.0 : 0.0);
-#pragma unroll
-      for (int f = 0; f < F - 1; f++)
-        put((q + 1) * F + 1 + f, hq ? lmap(row[q][f], f) : 0.0);
-    }
-  };
-  if (obs && c.obs_f64) {
-    if (valid) emit([&](int k, double val) { ((double *)obs)[i * (5 * F) + k] = val; });
-  } else if (obs) {
-    // float32 rows: stage the wave's rows in LDS, then write them as ONE contiguous run per wave
-    // (a lane's 5F floats are 100/120 B apart from its neighbour's: direct stores would touch 64
-    // different cache lines per instruction and tripled the measured WRITE_SIZE).
-    constexpr int S = 5 * F;
-    float *sw;
-    if constexpr (LEND) {
-      sw = stage + (threadIdx.x >> 6) * (64 * S);  // the caller lends LDS it no longer needs
-    } else {
-      __shared__ float s_obs[4][64 * S];
-      sw = s_obs[threadIdx.x >> 6];
-    }
+  // the wave's LDS scratch: first the mailbox of the neighbour gather (5 doubles per lane), then the float32 row staging
+  float *sw;
+  if constexpr (LEND) {
+    sw = stage + (threadIdx.x >> 6) * (64 * S);  // the caller lends LDS it no longer needs
+  } else {
+    __shared__ float s_obs[4][64 * S];
+    sw = s_obs[threadIdx.x >> 6];
+  }
+  static_assert(64 * S * sizeof(float) >= 5 * 64 * sizeof(double), "the mailbox must fit in the row staging");
+  if (obs) {
     const int lane = lane_id();
-    const int slot = (lane / G) * c.N + a;  // valid lanes of a wave are contiguous in agent index
-    if (valid) emit([&](int k, double val) { sw[slot * S + k] = (float)val; });
+    double sps, cps;
+    if (sincos_h) { sps = sincos_h[0]; cps = sincos_h[1]; }  // the step kernel carries sin / cos of the heading along
+    else mmm_sincos(v.h, &sps, &cps);
+    const double vx = v.v * cps, vy = v.v * sps;  // Vehicle.velocity kinematics.py:215-217
+    const double sx = lane_sx(v.lane);
+    // Every lane posts what its neighbours read of it (x, y, vx, vy, heading) in the wave's mailbox; the rows of the 4
+    // nearest are then GATHERED from their owners' columns by lane index instead of being dragged through the partner
+    // loop as 4 x 5 select chains (one v_cndmask pair per double, partner and row: 280 of them at G = 8).
+    double *mb = (double *)sw;
+    mb[0 * 64 + lane] = v.x; mb[1 * 64 + lane] = v.y; mb[2 * 64 + lane] = vx; mb[3 * 64 + lane] = vy;
+    if (KIND == MM_ENV_V1) mb[4 * 64 + lane] = v.h;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const long long e0 = (i - a) / c.N - lane / G;  // first env of this wave (i = e*N + a on every lane)
-    long long nenv = (long long)c.E - e0;
-    nenv = nenv < 0 ? 0 : (nenv > 64 / G ? 64 / G : nenv);
-    const int total = (int)nenv * c.N * S;
-    float *dst = (float *)obs + e0 * c.N * S;
-    if constexpr (S % 2 == 0) {
-      for (int t = lane; t < total / 2; t += 64) ((float2 *)dst)[t] = ((const float2 *)sw)[t];
+    // pass 1: sort keys of close_vehicles_to (road.py:257-267): |lane_distance_to|, inf if not within 180 m
+    double key[G];
+    key[0] = 0;
+    for_partners<G>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      const int pl = lane ^ m;
+      double px = mb[0 * 64 + pl], py = mb[1 * 64 + pl];
+      bool pp = dppx_i<m>((int)v.present) != 0;
+      double dx = px - v.x, dy = py - v.y;
+      bool close = pp && (dx * dx + dy * dy) < kT180;  // norm < PERCEPTION_DISTANCE, sqrt-free
+      key[m] = close ? fabs((px - sx) - (v.x - sx)) : INFINITY;
+    });
+    // pass 2: the 4 nearest in stable order become rows 1..4: sel[q] = the partner offset m of row q (0: none)
+    int sel[4] = {0, 0, 0, 0};
+    for_partners<G>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      int rank = 0;
+#pragma unroll
+      for (int m2 = 1; m2 < G; m2++)
+        if (m2 != m) rank += (key[m2] < key[m] || (key[m2] == key[m] && (a ^ m2) < (a ^ m))) ? 1 : 0;
+      const bool use = key[m] < INFINITY;
+#pragma unroll
+      for (int q = 0; q < 4; q++) sel[q] = (use && rank == q) ? m : sel[q];
+    });
+    double row[4][F - 1];
+    bool have[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      have[q] = sel[q] != 0;
+      const int pl = lane ^ sel[q];  // (no row: my own column, masked below)
+      row[q][0] = mb[0 * 64 + pl] - v.x; row[q][1] = mb[1 * 64 + pl] - v.y;
+      row[q][2] = mb[2 * 64 + pl] - vx; row[q][3] = mb[3 * 64 + pl] - vy;
+      if (KIND == MM_ENV_V1) {
+        double ph = mb[4 * 64 + pl];
+        if (c.steer_vel) {  // MDPLCVehicle.to_dict under "steer_vel" (safe_controller.py:75-81):
+          const int pkind = shfl_i(v.kind, pl);  // a CAV neighbour's heading is relative to the observer's
+          if (pkind == 1) ph = ph - v.h;
+        }
+        row[q][F - 2] = ph;
+      }
+    }
+    // the mailbox is read: the same LDS now stages the rows
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // normalize_obs :181-193 via utils.lmap :16-18 (no clip); ranges :171-176, :238-239
+    const double lo[5] = {-5.0 * 30, -12, -1.5 * 30, -1.5 * 30, -kPi / 2};
+    const double span[5] = {300.0, 24.0, 90.0, 90.0, kPi / 2 - (-kPi / 2)};  // x[1] - x[0] of lmap
+    const double ispan[5] = {1.0 / 300.0, 1.0 / 24.0, 1.0 / 90.0, 1.0 / 90.0, 1.0 / (kPi / 2 - (-kPi / 2))};
+    auto lmap = [&](double val, int f) { return -1 + div_c((val - lo[f]) * (1 - (-1)), span[f], ispan[f]); };
+    const double ego[5] = {v.x, v.y, vx, vy, v.h};
+    auto emit = [&](auto put) {
+      put(0, ctrl ? 1.0 : 0.0);
+#pragma unroll
+      for (int f = 0; f < F - 1; f++) put(1 + f, ctrl ? lmap(ego[f], f) : 0.0);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const bool hq = ctrl && have[q];
+        put((q + 1) * F, hq ? 1.0 : 0.0);
+#pragma unroll
+        for (int f = 0; f < F - 1; f++)
+          put((q + 1) * F + 1 + f, hq ? lmap(row[q][f], f) : 0.0);
+      }
+    };
+    if (c.obs_f64) {
+      if (valid) emit([&](int k, double val) { ((double *)obs)[i * (5 * F) + k] = val; });
     } else {
-      for (int t = lane; t < total; t += 64) dst[t] = sw[t];
+      // float32 rows: stage the wave's rows in LDS, then write them as ONE contiguous run per wave
+      // (a lane's 5F floats are 100/120 B apart from its neighbour's: direct stores would touch 64
+      // different cache lines per instruction and tripled the measured WRITE_SIZE).
+      const int slot = (lane / G) * c.N + a;  // valid lanes of a wave are contiguous in agent index
+      if (valid) emit([&](int k, double val) { sw[slot * S + k] = (float)val; });
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const long long e0 = (i - a) / c.N - lane / G;  // first env of this wave (i = e*N + a on every lane)
+      long long nenv = (long long)c.E - e0;
+      nenv = nenv < 0 ? 0 : (nenv > 64 / G ? 64 / G : nenv);
+      const int total = (int)nenv * c.N * S;
+      float *dst = (float *)obs + e0 * c.N * S;
+      if constexpr (S % 2 == 0) {
+        for (int t = lane; t < total / 2; t += 64) ((float2 *)dst)[t] = ((const float2 *)sw)[t];
+      } else {
+        for (int t = lane; t < total; t += 64) dst[t] = sw[t];
+      }
     }
   }
   // action mask: with masking on, the reference's `[[0]*n_a]*n` aliases every row (abstract.py:202,475)
