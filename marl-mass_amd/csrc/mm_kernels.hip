@@ -908,8 +908,13 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   // 100 B/lane of scratch costs ~8 % of the kernel): the LC-veto candidate B, the history records,
   // the previous safe action, the target speed, and the 7..15 sort keys of the classification pass.
   // (C_GU0 / C_GU1: parallel form only -- the g*u product of my pre- / post-step record for the askers' gather)
-  enum { C_B = 0, C_H1X = 8, C_H1VX, C_H2X, C_H2VX, C_SSTEER, C_SACC, C_TSPEED, C_A = 15, C_GU0 = 23, C_GU1 = 24, kColdB = 25 };
-  // candidates occupy 8 slots each (x, y, h, g.vx, cos h, steering, pose code, sin h); unshielded kernels use only slots
+  // (C_PRE, C_MSGW: parallel form only -- my pre-step pose (x, y, h, pose code) and my rank word, the mailbox the
+  // partners' classification reads instead of a DPP exchange per field)
+  enum { C_B = 0, C_H1X = 8, C_H1VX, C_H2X, C_H2VX, C_SSTEER, C_SACC, C_TSPEED, C_A = 15, C_GU0 = 23, C_GU1 = 24, C_PRE = 25, C_MSGW = 29 };
+  // (16-lane groups keep the DPP exchange: 5 more slots would cost them a wave per CU -- measured 0.456 -> 0.504 ms at N = 12)
+  constexpr bool kMailbox = G <= 8;
+  constexpr int kColdB = kMailbox ? 30 : 25;
+  // candidates occupy 8 slots each (x, y, h, pose code [int], cos h, steering, g.vx, sin h); unshielded kernels use only slots
   // 8..14 (+ the obs staging: 15 slots); the sort keys are a parallel-form temporary
   constexpr bool kRoomy = false;  // (round 1 parked cos(heading) / g.vx in LDS as well: no longer measurable, 0.332 ms either way)
   constexpr int C_CPSI = kColdB + G - 1, C_GVX = C_CPSI + 1;
@@ -917,6 +922,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   static_assert(kColdN * MM_STEP_BLOCK * 8 >= (MM_STEP_BLOCK / 64) * 64 * 30 * 4, "the obs staging must fit in the cold slots");
   __shared__ double s_cold[kColdN][MM_STEP_BLOCK];
   const int tid = threadIdx.x;
+  auto cold_i = [&](int slot, int col) -> int & { return ((int *)&s_cold[slot][col])[0]; };  // an int kept in a slot's low word
   if (LC) {
     s_cold[C_H1X][tid] = v.h1x; s_cold[C_H1VX][tid] = v.h1vx; s_cold[C_H2X][tid] = v.h2x; s_cold[C_H2VX][tid] = v.h2vx;
     s_cold[C_SSTEER][tid] = v.safe_steer; s_cold[C_SACC][tid] = v.safe_acc;
@@ -1045,8 +1051,8 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
       constexpr int base = decltype(base_c)::value;
       if constexpr (SHIELDED) {
         s_cold[base + 0][tid] = cc.x; s_cold[base + 1][tid] = cc.y; s_cold[base + 2][tid] = cc.h;
-        s_cold[base + 3][tid] = cc.gvx; s_cold[base + 4][tid] = cc.cpsi; s_cold[base + 5][tid] = steer;
-        s_cold[base + 6][tid] = (double)cc.pk; s_cold[base + 7][tid] = cc.spsi;
+        cold_i(base + 3, tid) = cc.pk; s_cold[base + 4][tid] = cc.cpsi; s_cold[base + 5][tid] = steer;
+        s_cold[base + 6][tid] = cc.gvx; s_cold[base + 7][tid] = cc.spsi;
       }
     };
     park(std::integral_constant<int, C_A>{}, cA, v.act_steer);
@@ -1077,8 +1083,8 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         const int base = useB ? C_B : C_A;  // both candidates sit in LDS; A's registers are free meanwhile
         Cand cc;
         cc.x = s_cold[base + 0][tid]; cc.y = s_cold[base + 1][tid]; cc.h = s_cold[base + 2][tid];
-        cc.gvx = s_cold[base + 3][tid]; cc.cpsi = s_cold[base + 4][tid]; cc.spsi = s_cold[base + 7][tid];
-        const int pk = (int)s_cold[base + 6][tid];
+        cc.gvx = s_cold[base + 6][tid]; cc.cpsi = s_cold[base + 4][tid]; cc.spsi = s_cold[base + 7][tid];
+        const int pk = cold_i(base + 3, tid);
         cc.pk = pk; cc.lane = pk & 7;
         return cc;
       }
@@ -1113,23 +1119,49 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
         // can a vehicle have more than 5 others around it at all?  (compile-time only: making the 8-lane kernels
         // test st.N > 6 as well cost them 3 % through 20 B/lane more scratch)
         constexpr bool count5 = G > 4;
+        if constexpr (kMailbox) { s_cold[C_PRE + 0][tid] = v.x; s_cold[C_PRE + 1][tid] = v.y; s_cold[C_PRE + 2][tid] = v.h; cold_i(C_PRE + 3, tid) = pk_self; }
         for (int pass = 0; pass <= st.N; pass++) {
-          const Cand mine = chosen(use_B);
+          const double mine_gvx = s_cold[(use_B ? C_B : C_A) + 6][tid];  // g.vx of the candidate I commit
           const double h1vx_mine = s_cold[C_H1VX][tid];
           s_cold[C_GU0][tid] = slot_gu<MASS>(s_cold[C_H2VX][tid], MASS ? s_cold[C_SACC][tid] : kCbfAccLo, GVX(), dt);
-          s_cold[C_GU1][tid] = slot_gu<MASS>(h1vx_mine, kCbfAccLo, mine.gvx, dt);  // (MASS: the rounds exchange the live value)
+          s_cold[C_GU1][tid] = slot_gu<MASS>(h1vx_mine, kCbfAccLo, mine_gvx, dt);  // (MASS: the rounds exchange the live value)
+          // my rank word: rank (99: not live) | bit 8: the candidate I commit is B.  With the pre-step pose posted above and
+          // both candidate images in LDS, a partner picks what it sees of me by address -- my committed post-state if I step
+          // before it, else my pre-step pose -- instead of receiving 3 doubles + 2 ints through DPP and select chains
+          if constexpr (kMailbox) {
+            cold_i(C_MSGW, tid) = (live ? rank : 99) | (use_B ? 256 : 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
+          Cand mine;  // (DPP exchange only)
+          if constexpr (!kMailbox) mine = chosen(use_B);
           double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
           int j_ol = -1, j_oa = -1, j_oar = -1;
           for_partners<G>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
             const int p = a ^ m;
-            const int p_rank = dppx_i<m>(live ? rank : 99);
-            const bool i_first = live && rank < p_rank;  // I step before this partner
-            // message: my pose as that partner sees it (post-state if I step before it, else pre-state)
-            const double sx_ = i_first ? mine.x : v.x, sy_ = i_first ? mine.y : v.y, sh_ = i_first ? mine.h : v.h;
-            const int spk = i_first ? mine.pk : pk_self;
-            const double ox = dppx_d<m>(sx_), oy = dppx_d<m>(sy_), oh = dppx_d<m>(sh_);
-            const int opk = dppx_i<m>(spk | (int)live << 8);
+            int p_rank, opk;
+            double ox, oy, oh;
+            bool i_first;
+            if constexpr (kMailbox) {
+              const int pl = tid ^ m;
+              const int pw = cold_i(C_MSGW, pl);
+              p_rank = pw & 255;
+              i_first = live && rank < p_rank;                      // I step before this partner
+              // its pose as I see it: the committed post-state if it steps before me, else the pre-step pose
+              const int pb = (!i_first && p_rank < 99) ? ((pw & 256) ? (int)C_B : (int)C_A) : (int)C_PRE;
+              ox = s_cold[pb + 0][pl]; oy = s_cold[pb + 1][pl]; oh = s_cold[pb + 2][pl];
+              opk = cold_i(pb + 3, pl) | (p_rank < 99 ? 256 : 0);
+            } else {
+              p_rank = dppx_i<m>(live ? rank : 99);
+              i_first = live && rank < p_rank;
+              // message: my pose as that partner sees it (post-state if I step before it, else pre-state)
+              const double sx_ = i_first ? mine.x : v.x, sy_ = i_first ? mine.y : v.y, sh_ = i_first ? mine.h : v.h;
+              const int spk = i_first ? mine.pk : pk_self;
+              ox = dppx_d<m>(sx_); oy = dppx_d<m>(sy_); oh = dppx_d<m>(sh_);
+              opk = dppx_i<m>(spk | (int)live << 8);
+            }
             const bool o_first = !i_first && p_rank < 99;  // partner steps before me (ranks are distinct)
             const Rel r = relate(v.x, v.y, pk_self, ((opk >> 8) & 1) != 0, ox, oy, oh, opk);
             if constexpr (count5) s_cold[kColdB + m - 1][tid] = r.key;
@@ -1195,7 +1227,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
           const ShieldStatic ss = shield_static<MASS>(c, v, cpsi_now, pk_self, nb);
           for (int round = 0; round <= st.N; round++) {
             if (MASS) {
-              const double gu_cur = slot_gu<true>(h1vx_mine, acc_cur, mine.gvx, dt);  // my post-step record under my current decision
+              const double gu_cur = slot_gu<true>(h1vx_mine, acc_cur, mine_gvx, dt);  // my post-step record under my current decision
               const double da = shfl_d(gu_cur, src_ol), db = shfl_d(gu_cur, src_oa);
               if (ol_dyn) nb.ol_gu = da;
               if (oa_dyn) nb.oa_gu = db;
