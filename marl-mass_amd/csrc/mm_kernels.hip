@@ -825,16 +825,19 @@ MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
 #ifndef MM_MIN_WAVES
 #define MM_MIN_WAVES 2  // 2 waves/SIMD: measured 0.62 ms vs 0.98 (1) / 0.92 (3, spills) at 65536x8 MASS
 #endif
-// Unshielded kernels are small (30 KB LDS, 189 VGPRs unconstrained): at 4 waves/SIMD (128 VGPRs, 128 B/lane
-// of spills) the extra latency hiding wins: 0.247 -> 0.203 ms at 65536 x 8 (3 waves: 0.231, 5: 0.267, 6: 0.240).
+// Unshielded kernels are small (7.7 KB LDS per wave): 3 waves/SIMD (168 VGPRs).  Measured at 65536 x 8, round 2:
+// 0.157 (2 waves) / 0.133 (3) / 0.135 (4: 128 VGPRs, ~80 B/lane of spills) / 0.165 ms (5).
 #ifndef MM_NONE_WAVES
-#define MM_NONE_WAVES 4
+#define MM_NONE_WAVES 3
+#endif
+#ifndef MM_IPM_WAVES
+#define MM_IPM_WAVES 2
 #endif
 template <int G, int SHIELD, bool MIXED>
 #ifndef MM_GENERAL_NONE_WAVES
 #define MM_GENERAL_NONE_WAVES 3  // mixed-traffic unshielded: 0.49 (2 waves) / 0.445 (3) / 0.51 ms (4)
 #endif
-constexpr int step_min_waves() { return SHIELD == MM_SHIELD_NONE ? (MIXED ? MM_GENERAL_NONE_WAVES : MM_NONE_WAVES) : MM_MIN_WAVES; }
+constexpr int step_min_waves(bool ipm = false) { return SHIELD == MM_SHIELD_NONE ? (MIXED ? MM_GENERAL_NONE_WAVES : MM_NONE_WAVES) : (ipm ? MM_IPM_WAVES : MM_MIN_WAVES); }
 // IPM: the MM_QP_IPM fidelity mode (the shield's QP by cvxopt's interior-point algorithm, include/mm_qp.h); carried by
 // general (MIXED) instantiations only, which run the literal sweep -- one QP per vehicle per sub-step, as the reference
 // TRACE: the per-sub-step trace planes (MMStepOut.trace, tests / profile export) are a compile-time property: the
@@ -843,7 +846,7 @@ template <int G, int KIND, int SHIELD, bool MIXED, bool IPM = false, bool TRACE 
 #ifndef MM_STEP_BLOCK
 #define MM_STEP_BLOCK 64  // one wave per workgroup: waves of a 256-thread block drifted ~12 % apart and the block held its LDS until the slowest was done (0.355 -> 0.333 ms)
 #endif
-__global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
+__global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IPM))) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
                                                    MMStepOut out, double *metrics) {
   constexpr bool LC = (KIND == MM_ENV_V1);
   constexpr bool SHIELDED = LC && (SHIELD != MM_SHIELD_NONE);
@@ -851,16 +854,17 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
   static_assert(!IPM || SHIELDED, "the IPM mode lives in shielded kernels");
   // Form of the shield sweep.  Every CAV-only shielded kernel (HSS and MASS) runs the parallel fixed-point form with the
   // literal front-to-back sweep compiled in as fallback (a vehicle moving backwards in x) and as the validation form
-  // (debug_flags bit0); the general kernels (HDVs / steer_vel) and the IPM kernels carry the literal sweep ONLY
-  // (kSerialOnly): the HDV "digital twin" branch is only expressible there, and the IPM solves one QP per vehicle per
-  // sub-step as the reference does.  See DESIGN.md section 2.
+  // (debug_flags bit0); the general kernels (HDVs / steer_vel) and the MASS IPM kernels carry the literal sweep ONLY
+  // (kSerialOnly): the HDV "digital twin" branch is only expressible there.  See DESIGN.md section 2.
 #ifdef MM_SERIAL_ALL  // tuning switch: every shielded kernel carries the literal sweep only
   constexpr bool kSerialOnly = true || IPM;
 #else
 #ifdef MM_SERIAL_MASS  // tuning switch: MASS in the literal form at every size
   constexpr bool kSerialOnly = MIXED || MASS || IPM;
 #else
-  constexpr bool kSerialOnly = MIXED || IPM;  // the IPM solves one QP per vehicle per sub-step, in sweep order, as the reference does
+  // (IPM + MASS: a follower's QP reads its leader's DECIDED acceleration bit for bit, so every round of the fixed point would
+  // be a full interior-point solve on all lanes -- the literal sweep is cheaper; IPM + HSS has no such coupling)
+  constexpr bool kSerialOnly = MIXED || (IPM && MASS);
 #endif
 #endif
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1232,7 +1236,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
               if (ol_dyn) nb.ol_gu = da;
               if (oa_dyn) nb.oa_gu = db;
             }
-            so = shield_dyn<MASS, true>(c, v, ss, nb);
+            so = shield_dyn<MASS, true, IPM>(c, v, ss, nb, shield_on);
             const double acc_next = shield_on ? so.acc : v.act_acc;
             const bool changed = __double_as_longlong(acc_next) != __double_as_longlong(acc_cur);
             acc_cur = acc_next;
@@ -1253,6 +1257,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>())
 #endif
         if (!serial && shield_on) {
           new_acc = so.acc; veto = so.veto; new_flags = so.flags; qt = so.qt;
+          if (IPM && so.bounds) atomicOr(c.err, MM_LATCH_QP_BOUNDS);  // check_bounds on the QP this vehicle finally solved
         }
        }
       }
