@@ -92,6 +92,14 @@ def run_case(E, N, steps, probs, kw):
                 return "step %d: info[%s]" % (t, k)
         if kw["trace"] and not torch.equal(gpu.trace.cpu().nan_to_num(nan=-7.0), cpu.trace.nan_to_num(nan=-7.0)):
             return "step %d: trace" % t
+        if t % 9 == 8 and kw["env_id"].endswith("v1") and kw["config"]["safety_guarantee"] != "none":
+            # the stand-alone shield entry (safety_layer(...) on the current state, nothing is mutated)
+            steer = (torch.rand(E, N, dtype=torch.float64, generator=g) - 0.5) * 0.3
+            acc = (torch.rand(E, N, dtype=torch.float64, generator=g) - 0.5) * 12
+            for x, y in zip(gpu.shield_actions(steer, acc), cpu.shield_actions(steer, acc)):
+                if not torch.equal(x.cpu().nan_to_num(nan=-7.0) if x.is_floating_point() else x.cpu(),
+                                   y.nan_to_num(nan=-7.0) if y.is_floating_point() else y):
+                    return "step %d: shield_actions" % t
     return None
 
 
