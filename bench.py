@@ -141,6 +141,11 @@ def main():
     ap.add_argument("--env-id", default="merge-multi-agent-v1")
     ap.add_argument("--obs-f64", action="store_true")
     ap.add_argument("--hdv", type=int, default=0, help="mixed traffic: the last HDV of the --agents vehicles are IDM/MOBIL HDVs (not the headline workload)")
+    ap.add_argument("--traffic-density", type=int, default=0, choices=(0, 1, 2, 3),
+                    help="1..3: every (re)spawn DRAWS its vehicle counts like MergeEnv._num_vehicles (merge_env_v1.py:180-211); --agents is "
+                         "then the slot capacity (>= 6 / 8 / 11) of a ragged batch and agent-steps count the vehicles actually present "
+                         "(the reference's training distribution; not the headline workload)")
+    ap.add_argument("--mixed-traffic", action="store_true", help="with --traffic-density: CAVs + IDM/MOBIL HDVs (traffic_type=mixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fidelity-line", action="store_true", help="skip the short qp_solver=ipm measurement appended to the headline line")
     ap.add_argument("--cpu-envs", type=int, default=32768)
@@ -181,6 +186,10 @@ def main():
     cfg = {"safety_guarantee": SHIELDS[args.shield], "HEADWAY_TIME": 0.5 if args.shield != "none" else 1.2}
     kw = dict(cbf_eta=0.03125 if args.shield != "none" else 0.0, cbf_tau=cfg["HEADWAY_TIME"], seed=1000,
               auto_reset=True, obs_f64=args.obs_f64, n_hdv=args.hdv, qp_solver=args.qp_solver)
+    if args.traffic_density:
+        cfg.update({"traffic_density": args.traffic_density, "traffic_type": "mixed" if args.mixed_traffic else "cav",
+                    "mixed_traffic": args.mixed_traffic})
+        kw["draw_counts"] = True
     env = VecMergeEnv(E, N, env_id=args.env_id, config=cfg, device=dev, first_env=first_env, **kw)
     if os.environ.get("MM_BENCH_NO_METRICS"):  # tuning experiment: no in-kernel metric accumulation
         metrics = torch.zeros(8, dtype=torch.float64, device=dev)
@@ -230,8 +239,14 @@ def main():
     elapsed = float(tmax[0])
     m = metrics.cpu().tolist()
 
+    present = None
+    if args.traffic_density:  # ragged batch: count the vehicles that exist (the batch is stationary: one snapshot represents the window)
+        present = (env.u8[abi.B["KIND"]] != 0).sum().to(torch.float64).reshape(1)
+        if world > 1:
+            present = present.to(tmax.device); dist.all_reduce(present)
+        present = float(present[0])
     if rank == 0:
-        agent_steps = float(E_total) * N * args.steps
+        agent_steps = float(E_total) * N * args.steps if present is None else present * args.steps
         b_alg = algorithmic_bytes_per_agent_step(args.env_id, N)
         achieved = E * N * b_alg / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed PMC passes (profiles/traffic.json, written from
@@ -256,7 +271,7 @@ def main():
                         "frac": ach / (1024 * 2.4e9 / 1e12), "valu_insts_per_wave": sj["pmc_per_launch"]["SQ_INSTS_VALU"] / sj["pmc_per_launch"]["SQ_WAVES"]}
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass
-        headline = args.shield == "mass" and not args.hdv and args.env_id.endswith("v1") and N == 8 and args.qp_solver == "exact"
+        headline = args.shield == "mass" and not args.hdv and args.env_id.endswith("v1") and N == 8 and args.qp_solver == "exact" and not args.traffic_density
         if headline and E_total == 65536:
             # BASELINE.json's metric on its own config: 65 536 envs x 8 CAVs in total (1 GPU weak == c5's batch on one GPU;
             # 8 GPUs strong == c5 itself)
@@ -267,6 +282,9 @@ def main():
                 "agent-steps/sec (whole node), MASS CBF shield on, %d envs x 8 CAVs" % E_total
         else:
             metric = "agent-steps/sec (whole node), shield=%s, qp=%s, %d envs x %d vehicles" % (args.shield, args.qp_solver, E_total, N)
+        if present is not None:
+            metric += " [vehicle counts drawn per episode, traffic_density=%d%s: mean %.2f vehicles per env in %d slots]" % (
+                args.traffic_density, " mixed" if args.mixed_traffic else "", present / E_total, N)
         line = {
             "metric": metric,
             "value": agent_steps / elapsed, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps,
