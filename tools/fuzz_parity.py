@@ -56,7 +56,8 @@ def draw_case(rng):
               obs_f64=rng.random() < 0.5, seed=rng.randrange(1, 1 << 30), auto_reset=True, n_hdv=n_hdv,
               qp_solver="ipm" if (shielded and rng.random() < 0.2) else "exact", trace=rng.random() < 0.3,
               draw_counts=draw_counts)
-    E = rng.choice([64, 128, 256, 512]) if kw["qp_solver"] == "exact" else rng.choice([32, 64, 128])
+    # (odd batch sizes: the last wave of the launch is partly empty and an env group may be the only one in its wave)
+    E = rng.choice([64, 128, 256, 512, 1, 7, 37, 100, 333]) if kw["qp_solver"] == "exact" else rng.choice([32, 64, 128, 5, 45])
     steps = rng.choice([40, 80, 120, 210])
     probs = rng.choice([[0.1, 0.6, 0.1, 0.1, 0.1], [0.25, 0.3, 0.25, 0.1, 0.1], [0.2, 0.2, 0.2, 0.2, 0.2], [0.05, 0.1, 0.05, 0.6, 0.2],
                         [0.05, 0.1, 0.05, 0.1, 0.7]])
