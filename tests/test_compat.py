@@ -65,6 +65,20 @@ def test_reset_matches_reference_mixed_traffic(resets):
         np.testing.assert_allclose(obs, np.array(row["obs"]), rtol=0, atol=1e-12)
 
 
+def test_reset_with_num_cav_matches_reference(resets):
+    """reset(num_CAV=k) (merge_env_v1.py:186-187,194-195,202-203; MAPPO.evaluation's fixed-CAV-count episodes): the CAV count
+    is taken, only the HDV count is drawn -- CAV-only traffic turns the drawn HDVs into CAVs as well (:206-209)."""
+    for row in resets["numcav"]:
+        env = compat.MergeEnvCompat("merge-multi-agent-v1", backend_factory=_factory)
+        env.config.update({"traffic_density": row["td"], "traffic_type": row["tt"], "mixed_traffic": row["tt"] == "mixed",
+                           "safety_guarantee": "none"})
+        env.reset(is_training=False, testing_seeds=row["seed"], num_CAV=row["num_CAV"])
+        n, n_all = row["n"], row["n_all"]
+        assert len(env.controlled_vehicles) == n and len(env.road.vehicles) == n_all and env.n_merge == row["n_merge"], row
+        np.testing.assert_array_equal(env._b.f64[:5, 0, :n_all].numpy().T, np.array(row["f"]))
+        np.testing.assert_array_equal(env._b.u8[abi.B["KIND"], 0, :n_all].numpy(), np.array(row["kind"]))
+
+
 def test_training_seed_increments():
     env = compat.MergeEnvCompat("merge-multi-agent-v1", backend_factory=_factory)
     env.config["traffic_type"] = "cav"

@@ -127,15 +127,18 @@ def _place_vehicles(env, placement):
     road.vehicles, env.controlled_vehicles = [], []
     for k, row in enumerate(placement):
         x, y, speed = row[:3]
-        v = env._make_ego_vehicle(road=road, position=np.array([x, y], dtype=float), speed=speed, veh_id=k)
-        if len(row) > 3:  # Vehicle.__init__(heading=...) (kinematics.py:36-53): lane index from the heading too
+        hdv = len(row) > 4 and row[4] == "h"  # an IDM / MOBIL vehicle (merge_env_v1.py:344-362); HDVs follow the CAVs
+        make = env._make_hdv_vehicle if hdv else env._make_ego_vehicle
+        v = make(road=road, position=np.array([x, y], dtype=float), speed=speed, veh_id=k)
+        if len(row) > 3 and row[3] is not None:  # Vehicle.__init__(heading=...) (kinematics.py:36-53): lane index from the heading too
             v.heading = float(row[3])
             v.lane_index = road.network.get_closest_lane_index(v.position, v.heading)
             v.lane = road.network.get_lane(v.lane_index)
             v.target_lane_index = v.lane_index
-        env.controlled_vehicles.append(v)
+        if not hdv:
+            env.controlled_vehicles.append(v)
         road.vehicles.append(v)
-    env._record_vehicle_count(n_merge=sum(1 for row in placement if row[1] > 5))
+    env._record_vehicle_count(n_merge=sum(1 for row in placement if row[1] > 5 and not (len(row) > 4 and row[4] == "h")))
     env.define_spaces()
     obs = env.observation_type.observe()
     return np.asarray(obs).reshape((len(obs), -1))
@@ -410,8 +413,19 @@ def gen_reset():
                                   n_all=len(env.road.vehicles), n_merge=int(env.n_merge),
                                   f=np.array(f)[:, :5].tolist(), timer=np.nan_to_num(np.array(f)[:, 10]).tolist(),
                                   kind=np.array(i)[:, 8].tolist(), obs=np.asarray(obs).tolist()))
+    # reset(num_CAV=k): only the HDV count is drawn (merge_env_v1.py:186-187,194-195,202-203), as MAPPO.evaluation can ask
+    numcav = []
+    for tt in ("cav", "mixed"):
+        for td, k in ((1, 2), (2, 3), (3, 5), (1, 1)):
+            for seed in (0, 25):
+                env = gym.make("merge-multi-agent-v1")
+                env.config.update({"traffic_density": td, "traffic_type": tt, "mixed_traffic": tt == "mixed", "safety_guarantee": "none"})
+                env.reset(is_training=False, testing_seeds=seed, num_CAV=k)
+                f, i = zip(*[_veh_snapshot(v) for v in env.road.vehicles])
+                numcav.append(dict(td=td, tt=tt, seed=seed, num_CAV=k, n=len(env.controlled_vehicles), n_all=len(env.road.vehicles),
+                                   n_merge=int(env.n_merge), f=np.array(f)[:, :5].tolist(), kind=np.array(i)[:, 8].tolist()))
     with open(os.path.join(OUT, "reset.json"), "w") as fh:
-        json.dump(dict(fixed=rows, drawn=counts, mixed=mixed), fh)
+        json.dump(dict(fixed=rows, drawn=counts, mixed=mixed, numcav=numcav), fh)
     print("reset.json: %d fixed-count resets, %d drawn-count resets" % (len(rows), len(counts)))
 
 
@@ -526,6 +540,21 @@ def main():
     for tag, shield in (("hss", "cbf-avs_cint"), ("mass", "cbf-cav")):
         metas.append(run_episode("ed_v1_odd_%s" % tag, v1, shield, 4, 0, 0, 0.5, 0.03125, max_steps=8,
                                  scripted=[(I, I, I, A["FASTER"])], placement=odd))
+    #  pile-ups: check_collision returns at once for an already-crashed vehicle (kinematics.py:185-186), so in the
+    #  creation-order pair loop (road.py:288-292) a third overlapping vehicle stays intact -- incl. out-of-order creation
+    for tag, xs in (("a", (100.0, 103.0, 106.0)), ("b", (100.0, 102.0, 104.0)), ("c", (100.0, 104.0, 102.0)), ("d", (104.0, 100.0, 102.0, 140.0))):
+        metas.append(run_episode("ed_v0_pileup_%s" % tag, v0, "none", len(xs), 0, 0, 1.2, 0.0, max_steps=3,
+                                 scripted=[(I,) * len(xs)], placement=[(x, 0.0, 20.0) for x in xs]))
+    metas.append(run_episode("ed_v1_pileup_mass", v1, "cbf-cav", 3, 0, 0, 0.5, 0.03125, max_steps=3,
+                             scripted=[(I, I, I)], placement=[(100.0, 0.0, 20.0), (103.0, 0.0, 21.0), (106.0, 0.0, 19.0)]))
+    #  crashed HDVs: an HDV-HDV crash does not end the episode (merge_env_v1.py:168-178 looks at controlled vehicles only);
+    #  the wrecks stop acting (behavior.py:83-84), brake by clip_actions' crashed branch (kinematics.py:144-146) and a CAV
+    #  approaches them with and without a shield
+    wreck = [(60.0, 0.0, 25.0), (20.0, 10.5, 24.0), (150.0, 0.0, 22.0, None, "h"), (153.0, 0.0, 18.0, None, "h"), (100.0, 10.5, 20.0, None, "h")]
+    for tag, shield in (("none", "none"), ("hss", "cbf-avs_cint"), ("mass", "cbf-cav")):
+        metas.append(run_episode("ed_v1_wreck_%s" % tag, v1, shield, 2, 0, 0, 0.5, 0.03125, max_steps=40,
+                                 scripted=[(I, I)], placement=wreck, n_hdv=3))
+    metas.append(run_episode("ed_v0_wreck", v0, "none", 2, 0, 0, 1.2, 0.0, max_steps=40, scripted=[(I, A["FASTER"])], placement=wreck, n_hdv=3))
     # the index is rebuilt from the tapes on disk, so a partial regeneration (`only <prefix> ...`) keeps the rest
     import glob
     metas = []
