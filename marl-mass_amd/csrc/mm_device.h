@@ -69,7 +69,12 @@ MM_DEV double py_mod(double a, double b) {  // Python float % for b > 0: result 
   }
   return m;
 }
-MM_DEV double wrap_to_pi(double x) { return py_mod(x + kPi, 2 * kPi) - kPi; }  // utils.py:40-41
+MM_DEV double wrap_to_pi(double x) {  // utils.py:40-41
+  const double a = x + kPi;
+  // every lane of the wave already inside [0, 2 pi) (any heading difference on this path): py_mod returns `a` itself there
+  if (__all(a >= 0.0 && a < 2 * kPi)) return a - kPi;
+  return py_mod(a, 2 * kPi) - kPi;
+}
 MM_DEV double not_zero(double x) {                                              // utils.py:31-37
   return fabs(x) > 1e-2 ? x : (x > 0 ? 1e-2 : -1e-2);
 }

@@ -452,15 +452,22 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
     });
     // pass 2: the 4 nearest in stable order become rows 1..4: sel[q] = the partner offset m of row q (0: none)
     int sel[4] = {0, 0, 0, 0};
+    int rank[G];  // position of partner m in the stable order: (key, creation index) is a strict total order, so each
+#pragma unroll    // unordered pair is compared once and credited to the one that comes later
+    for (int m = 0; m < G; m++) rank[m] = 0;
+#pragma unroll
+    for (int m = 1; m < G; m++)
+#pragma unroll
+      for (int m2 = m + 1; m2 < G; m2++) {
+        const bool m2_first = key[m2] < key[m] || (key[m2] == key[m] && (a ^ m2) < (a ^ m));
+        rank[m] += m2_first ? 1 : 0;
+        rank[m2] += m2_first ? 0 : 1;
+      }
     for_partners<G>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      int rank = 0;
-#pragma unroll
-      for (int m2 = 1; m2 < G; m2++)
-        if (m2 != m) rank += (key[m2] < key[m] || (key[m2] == key[m] && (a ^ m2) < (a ^ m))) ? 1 : 0;
       const bool use = key[m] < INFINITY;
 #pragma unroll
-      for (int q = 0; q < 4; q++) sel[q] = (use && rank == q) ? m : sel[q];
+      for (int q = 0; q < 4; q++) sel[q] = (use && rank[m] == q) ? m : sel[q];
     });
     double row[4][F - 1];
     bool have[4];
@@ -513,7 +520,7 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const long long e0 = (i - a) / c.N - lane / G;  // first env of this wave (i = e*N + a on every lane)
+      const long long e0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x - lane) / G;  // first env of this wave (lane l of the launch holds env l / G; a shift, not a 64-bit division by N)
       long long nenv = (long long)c.E - e0;
       nenv = nenv < 0 ? 0 : (nenv > 64 / G ? 64 / G : nenv);
       const int total = (int)nenv * c.N * S;
