@@ -122,6 +122,16 @@ struct MMHandle_ {
   int latched; /* error raised inside step(), reported by mm_poll_errors (the HIP twin cannot return it from a launch) */
 };
 
+#ifdef ORC_QP_LOG
+/* Diagnostic build only (oracle/Makefile: libmm_oracle_qplog.so, used by tools/ipm_sched_model.py): one text line per
+ * shield QP -- env, sub-step clock, vehicle, sweep rank, IPM iterations, status, rows, and the vehicles whose decision of
+ * THIS sub-step the QP's right-hand side reads (leader / front-adjacent; -1: none) -- to model wave schedules on the CPU. */
+static FILE *g_qplog;
+static int g_qplog_env, g_qplog_rank, g_qplog_dep_ol, g_qplog_dep_oa;
+static unsigned g_qplog_stepped;
+void orc_qplog_open(const char *path) { if (g_qplog) fclose(g_qplog); g_qplog = path ? fopen(path, "w") : NULL; }
+#endif
+
 /* ------------------------------------------------------------------ utils.py */
 
 /* utils.py:40-41 wrap_to_pi with Python float % semantics (sign of the divisor) */
@@ -735,6 +745,9 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
   int constrain_adj = 0;
   int near[MM_MAX_AGENTS];
   int m = close_vehicles_to(e, i, PERCEPTION_DIST, 5, near);
+#ifdef ORC_QP_LOG
+  g_qplog_dep_ol = g_qplog_dep_oa = -1;
+#endif
   for (int k = 0; k < m; k++) {
     Veh *o = &e->v[near[k]];
     int v_a = is_adj_lane(veh, o->lane);
@@ -749,6 +762,9 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
       } else if (!s_oa.present && ld >= 0) {
         s_oa.present = 1; /* veh.state_hist[-2] */
         s_oa.x = o->h2[0]; s_oa.vx = o->h2[1]; /* heading / speed only feed the unused dpsi term */
+#ifdef ORC_QP_LOG
+        if (mass && o->kind == 1 && ((g_qplog_stepped >> near[k]) & 1u)) g_qplog_dep_oa = near[k];
+#endif
         if (mass) {
           if (o->kind == 1) { a_oa_acc = o->safe_acc; a_oa_steer = o->safe_steer; gp_oa = o->g_vx; }
           else { a_oa_acc = CBF_ACC_LO; a_oa_steer = 0; gp_oa = 1; } /* HDV: no safe_action / fg_params (:129-135) */
@@ -770,6 +786,9 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
     } else if (!s_ol.present && (is_same_lane(veh, o->lane) || appr) && ld > 0) {
       s_ol.present = 1;
       s_ol.x = o->h2[0]; s_ol.vx = o->h2[1];
+#ifdef ORC_QP_LOG
+      if (mass && o->kind == 1 && ((g_qplog_stepped >> near[k]) & 1u)) g_qplog_dep_ol = near[k];
+#endif
       if (mass) {
         if (o->kind == 1) { a_ol_acc = o->safe_acc; a_ol_steer = o->safe_steer; gp_ol = o->g_vx; }
         else { a_ol_acc = CBF_ACC_LO; a_ol_steer = 0; gp_ol = 1; }
@@ -781,12 +800,18 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
     if ((!s_ol.present || OBST_X <= s_ol.x) && fabs(OBST_Y - veh->y) <= 2) {
       s_ol.present = 1; s_ol.x = OBST_X; s_ol.heading = 0; s_ol.vx = 0.0;
       s_ol.speed = 0.0 / m_cos(0.0); /* "cos_h" branch of simplified_control */
+#ifdef ORC_QP_LOG
+      g_qplog_dep_ol = -1;
+#endif
       if (mass) { a_ol_acc = 0; a_ol_steer = 0; gp_ol = 0; }
     }
     double ady = fabs(OBST_Y - veh->y);
     if ((!s_oa.present || OBST_X <= s_oa.x) && (2 < ady && ady <= 4)) {
       s_oa.present = 1; s_oa.x = OBST_X; s_oa.heading = 0; s_oa.vx = 0.0;
       s_oa.speed = 0.0 / m_cos(0.0);
+#ifdef ORC_QP_LOG
+      g_qplog_dep_oa = -1;
+#endif
       if (mass) { a_oa_acc = 0; a_oa_steer = 0; gp_oa = 0; constrain_adj = 0; }
     }
   }
@@ -847,6 +872,11 @@ static int safety_layer(const MMConfig *cfg, Env *e, int i, double dt, double *s
     const double hh[4] = {h0, h1, h2, h3};
     int iters;
     veh->qp_optimal = qp_ipm_cbf(a, hh, rows, &d, &iters);
+#ifdef ORC_QP_LOG
+    if (g_qplog)
+      fprintf(g_qplog, "%d %d %d %d %d %d %d %d %d\n", g_qplog_env, e->time, i, g_qplog_rank, iters, veh->qp_optimal, rows,
+              g_qplog_dep_ol, rows == 4 ? g_qplog_dep_oa : -1);
+#endif
   } else { /* exact KKT solution of min 1/2(d^2 + e^2 + 1e18 s^2): see tools/refshim/cvxopt */
     if (a > 0) d = fmin(0.0, hc / a);
     else if (a < 0) d = fmax(0.0, hc / a);
@@ -1034,9 +1064,18 @@ static int simulate(const MMConfig *cfg, Env *e, const int32_t *actions, double 
       else mdp_act(&e->v[order[r]], -1, is_lc);
     }
     sort_by_x_desc(e, order); /* road.step */
+#ifdef ORC_QP_LOG
+    g_qplog_stepped = 0; g_qplog_env = (int)(base / (e->n > 0 ? e->n : 1));
+#endif
     for (int r = 0; r < e->n; r++) {
+#ifdef ORC_QP_LOG
+      g_qplog_rank = r;
+#endif
       int rr = vehicle_step(cfg, e, order[r], dt);
       if (rr) rc = rr;
+#ifdef ORC_QP_LOG
+      g_qplog_stepped |= 1u << order[r];
+#endif
     }
     for (int i = 0; i < e->n; i++) { /* collision loop road.py:288-292, kinematics.py:175-200 */
       Veh *v = &e->v[i];
