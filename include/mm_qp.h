@@ -22,11 +22,15 @@
  * mm_qp_ipm_cbf below is the plain start / top / bottom loop for one QP (oracle, qp_kernel, literal sweep).
  * No MFMA: the largest dense object is a 3x3 Cholesky factor with two structural zeros.
  *
- * Divisions by the same denominator inside an iteration (the four scaling entries lambda_k: six each; the Cholesky
- * pivots: five and four) go through MM_QP_RCP / MM_QP_DIVR: by default a plain IEEE division; the device build
- * (mm_device.h) defines them as ONE refined reciprocal per denominator and a 4-instruction correctly rounded
- * quotient per numerator -- the same quotient bits (tests/test_hip_parity.py::test_qp_division_forms), a third of the
- * instructions.
+ * Written with scalar fields and straight-line code on purpose (no arrays, no loops): on the device every value
+ * must live in a register -- an array that is indexed by a loop variable or reached through a pointer ends up in
+ * scratch memory, and a scratch round trip inside the iteration costs more than the iteration.  The fourth row
+ * exists only with rows == 4 (MASS with constrain_adj, a few per cent of the QPs): everything that touches it sits
+ * in `if (m4)` blocks, which a wave skips when none of its lanes has one.
+ *
+ * Divisions by the same denominator inside an iteration (the scaling entries lambda_k: six each; the Cholesky
+ * pivots: five and four) go through MM_QP_RCP / MM_QP_DIVR, square roots through MM_QP_SQRT: by default plain IEEE
+ * operations; a device build may define cheaper forms with the same result bits (marl-mass_amd/csrc/mm_device.h).
  *
  * The includer defines MMM_FN (`static inline`, or `__device__ __forceinline__`); needs sqrt, fmin, fmax.
  * Build with -ffp-contract=off: a*b+c must keep two roundings here as in Python.
@@ -49,81 +53,95 @@
 #define MM_QP_RCP(b) (b)
 #define MM_QP_DIVR(a, b, R) ((a) / (b))
 #endif
+#ifndef MM_QP_DIV
+#define MM_QP_DIV(a, b) ((a) / (b))
+#endif
+#ifndef MM_QP_SQRT
+#define MM_QP_SQRT(x) sqrt(x)
+#endif
 
 typedef struct MMQpKkt {  /* misc.kkt_chol2 factor: S = P + Gs'Gs = L L', Gs = W^-1 G */
   double g0, g3;          /* Gs[0][0], Gs[3][0] = di * a  (Gs[k][2] = -di[k] for k = 0, 3; Gs[1][0] = di1, Gs[2][0] = -di2) */
   double l00, l20, l22;   /* L (L11 = 1, L10 = L21 = 0) */
   double r00, r22;        /* MM_QP_RCP of the pivots l00, l22 */
-  double di[4];
+  double di0, di1, di2, di3;
 } MMQpKkt;
 
 typedef struct MMQpState {
-  double a, h[4], resz0;        /* the problem; resz0 = max(1, |h|) */
-  double x0, x2, gap;           /* primal iterate (d, slack) and s'z */
-  double s[4], z[4];            /* slacks and multipliers */
-  double d[4], di[4], lmbda[4]; /* Nesterov-Todd scaling W = diag(d), W^-1, lambda = W^-1 s = W z (valid from the first mm_qp_bottom on) */
+  double a, h0, h1, h2, h3, resz0;  /* the problem; resz0 = max(1, |h|) */
+  double x0, x2, gap;               /* primal iterate (d, slack) and s'z */
+  double s0, s1, s2, s3, z0, z1, z2, z3;          /* slacks and multipliers */
+  double d0, d1, d2, d3, di0, di1, di2, di3;      /* Nesterov-Todd scaling W = diag(d) and W^-1 ... */
+  double l0, l1, l2, l3;                          /* ... lambda = W^-1 s = W z (valid from the first mm_qp_bottom on) */
   int m4, iters;
 } MMQpState;
-typedef struct MMQpRes { double rx0, rx2, rz[4]; } MMQpRes;  /* what mm_qp_top hands to mm_qp_bottom */
+typedef struct MMQpRes { double rx0, rx2, rz0, rz1, rz2, rz3; } MMQpRes;  /* what mm_qp_top hands to mm_qp_bottom */
 
-MMM_FN int mm_qp_factor(MMQpKkt *f, double a, int m4, const double *di) {
-  f->di[0] = di[0]; f->di[1] = di[1]; f->di[2] = di[2]; f->di[3] = m4 ? di[3] : 0.0;
-  f->g0 = di[0] * a;
-  f->g3 = m4 ? di[3] * a : 0.0;
-  double s00 = f->g0 * f->g0 + di[1] * di[1] + di[2] * di[2];
-  if (m4) s00 = s00 + f->g3 * f->g3;
+MMM_FN int mm_qp_factor(MMQpKkt *f, double a, int m4, double di0, double di1, double di2, double di3) {
+  f->di0 = di0; f->di1 = di1; f->di2 = di2; f->di3 = 0.0;
+  f->g0 = di0 * a;
+  f->g3 = 0.0;
+  double s00 = f->g0 * f->g0 + di1 * di1 + di2 * di2;
+  double s20 = 0.0 + (-di0) * f->g0;
+  double s22 = di0 * di0;
+  if (m4) {
+    f->di3 = di3;
+    f->g3 = di3 * a;
+    s00 = s00 + f->g3 * f->g3;
+    s20 = s20 + (-di3) * f->g3;
+    s22 = s22 + di3 * di3;
+  }
   s00 = s00 + 1.0;
-  double s20 = 0.0 + (-di[0]) * f->g0;
-  if (m4) s20 = s20 + (-di[3]) * f->g3;
-  double s22 = di[0] * di[0];
-  if (m4) s22 = s22 + di[3] * di[3];
   s22 = s22 + 1e18;
   if (!(s00 > 0.0)) return 0;
-  f->l00 = sqrt(s00);
+  f->l00 = MM_QP_SQRT(s00);
   f->r00 = MM_QP_RCP(f->l00);
   f->l20 = MM_QP_DIVR(s20, f->l00, f->r00);
   const double t = s22 - f->l20 * f->l20;
   if (!(t > 0.0)) return 0;
-  f->l22 = sqrt(t);
+  f->l22 = MM_QP_SQRT(t);
   f->r22 = MM_QP_RCP(f->l22);
   return 1;
 }
 /* [P G'; G -W'W][ux; W^-1 uz] = [bx; bz]; (x0, x2, z) hold the right-hand side on entry, the solution on exit */
-MMM_FN void mm_qp_solve(const MMQpKkt *f, int m4, double *x0, double *x2, double *z) {
-  z[0] = z[0] * f->di[0]; z[1] = z[1] * f->di[1]; z[2] = z[2] * f->di[2];
-  if (m4) z[3] = z[3] * f->di[3];
-  double t = 0.0 + f->g0 * z[0];
-  t = t + f->di[1] * z[1];
-  t = t + (-f->di[2]) * z[2];
-  if (m4) t = t + f->g3 * z[3];
+MMM_FN void mm_qp_solve(const MMQpKkt *f, int m4, double *x0, double *x2, double *z0, double *z1, double *z2, double *z3) {
+  double w0 = *z0 * f->di0, w1 = *z1 * f->di1, w2 = *z2 * f->di2, w3 = 0.0;
+  double t = 0.0 + f->g0 * w0;
+  t = t + f->di1 * w1;
+  t = t + (-f->di2) * w2;
+  double u = 0.0 + (-f->di0) * w0;
+  if (m4) {
+    w3 = *z3 * f->di3;
+    t = t + f->g3 * w3;
+    u = u + (-f->di3) * w3;
+  }
   double a0 = *x0 + t;
-  t = 0.0 + (-f->di[0]) * z[0];
-  if (m4) t = t + (-f->di[3]) * z[3];
-  double a2 = *x2 + t;
+  double a2 = *x2 + u;
   a0 = MM_QP_DIVR(a0, f->l00, f->r00);          /* trsv: L x = x */
   a2 = a2 - a0 * f->l20;
   a2 = MM_QP_DIVR(a2, f->l22, f->r22);
   a2 = MM_QP_DIVR(a2, f->l22, f->r22);          /* trsv 'T': L' x = x */
   t = a0 - f->l20 * a2;
   a0 = MM_QP_DIVR(t, f->l00, f->r00);
-  t = -z[0]; t = t + a0 * f->g0; t = t + a2 * (-f->di[0]); z[0] = t;
-  t = -z[1]; t = t + a0 * f->di[1]; z[1] = t;
-  t = -z[2]; t = t + a0 * (-f->di[2]); z[2] = t;
-  if (m4) { t = -z[3]; t = t + a0 * f->g3; t = t + a2 * (-f->di[3]); z[3] = t; }
+  t = -w0; t = t + a0 * f->g0; t = t + a2 * (-f->di0); *z0 = t;
+  t = -w1; t = t + a0 * f->di1; *z1 = t;
+  t = -w2; t = t + a0 * (-f->di2); *z2 = t;
+  if (m4) { t = -w3; t = t + a0 * f->g3; t = t + a2 * (-f->di3); *z3 = t; }
   *x0 = a0; *x2 = a2;
 }
-MMM_FN double mm_qp_dot(const double *p, const double *q, int m4) {
-  double t = 0.0 + p[0] * q[0];
-  t = t + p[1] * q[1];
-  t = t + p[2] * q[2];
-  if (m4) t = t + p[3] * q[3];
+/* sum_k p_k q_k in index order, one rounding per operation */
+MMM_FN double mm_qp_dot(double p0, double q0, double p1, double q1, double p2, double q2, double p3, double q3, int m4) {
+  double t = 0.0 + p0 * q0;
+  t = t + p1 * q1;
+  t = t + p2 * q2;
+  if (m4) t = t + p3 * q3;
   return t;
 }
-MMM_FN double mm_qp_maxneg(const double *p, int m4) {  /* misc.max_step for the 'l' cone */
-  double t = -p[0];
-  if (-p[1] > t) t = -p[1];
-  if (-p[2] > t) t = -p[2];
-  if (m4 && -p[3] > t) t = -p[3];
+MMM_FN double mm_qp_maxneg(double p0, double p1, double p2, double p3, int m4) {  /* misc.max_step for the 'l' cone */
+  double t = -p0;
+  if (-p1 > t) t = -p1;
+  if (-p2 > t) t = -p2;
+  if (m4 && -p3 > t) t = -p3;
   return t;
 }
 
@@ -132,56 +150,58 @@ MMM_FN double mm_qp_maxneg(const double *p, int m4) {  /* misc.max_step for the 
 MMM_FN int mm_qp_start(MMQpState *q, double a, double h0, double h1, double h2, double h3, int rows) {
   const int m4 = rows == 4;
   q->a = a; q->m4 = m4; q->iters = 0;
-  q->h[0] = h0; q->h[1] = h1; q->h[2] = h2; q->h[3] = m4 ? h3 : 0.0;
-  q->resz0 = fmax(1.0, sqrt(mm_qp_dot(q->h, q->h, m4)));  /* resx0 = max(1, |q|) = 1 */
+  q->h0 = h0; q->h1 = h1; q->h2 = h2; q->h3 = m4 ? h3 : 0.0;
+  q->resz0 = fmax(1.0, sqrt(mm_qp_dot(q->h0, q->h0, q->h1, q->h1, q->h2, q->h2, q->h3, q->h3, m4)));  /* resx0 = max(1, |q|) = 1 */
+  q->d0 = q->d1 = q->d2 = q->d3 = 1.0; q->di0 = q->di1 = q->di2 = q->di3 = 1.0; q->l0 = q->l1 = q->l2 = q->l3 = 1.0;
   MMQpKkt kkt;
-  const double one[4] = {1.0, 1.0, 1.0, 1.0};
-  if (!mm_qp_factor(&kkt, a, m4, one)) {
+  if (!mm_qp_factor(&kkt, a, m4, 1.0, 1.0, 1.0, 1.0)) {
     q->x0 = a - a + (h0 - h0); q->x2 = q->x0; q->gap = q->x0;  /* NaN stays NaN */
+    q->s0 = q->s1 = q->s2 = q->s3 = q->z0 = q->z1 = q->z2 = q->z3 = q->x0;
     return 0;
   }
-  double x0 = -0.0, x2 = -0.0, *s = q->s, *z = q->z;
-  z[0] = q->h[0]; z[1] = q->h[1]; z[2] = q->h[2]; z[3] = q->h[3];
-  mm_qp_solve(&kkt, m4, &x0, &x2, z);
-  s[0] = -z[0]; s[1] = -z[1]; s[2] = -z[2]; s[3] = -z[3];
-  double nrm = sqrt(mm_qp_dot(s, s, m4));
-  const double ts = mm_qp_maxneg(s, m4);
-  if (ts >= -1e-8 * fmax(nrm, 1.0)) { const double sh = 1.0 + ts; s[0] = s[0] + sh; s[1] = s[1] + sh; s[2] = s[2] + sh; s[3] = s[3] + sh; }
-  nrm = sqrt(mm_qp_dot(z, z, m4));
-  const double tz = mm_qp_maxneg(z, m4);
-  if (tz >= -1e-8 * fmax(nrm, 1.0)) { const double sh = 1.0 + tz; z[0] = z[0] + sh; z[1] = z[1] + sh; z[2] = z[2] + sh; z[3] = z[3] + sh; }
+  double x0 = -0.0, x2 = -0.0;
+  double z0 = q->h0, z1 = q->h1, z2 = q->h2, z3 = q->h3;
+  mm_qp_solve(&kkt, m4, &x0, &x2, &z0, &z1, &z2, &z3);
+  double s0 = -z0, s1 = -z1, s2 = -z2, s3 = -z3;
+  double nrm = sqrt(mm_qp_dot(s0, s0, s1, s1, s2, s2, s3, s3, m4));
+  const double ts = mm_qp_maxneg(s0, s1, s2, s3, m4);
+  if (ts >= -1e-8 * fmax(nrm, 1.0)) { const double sh = 1.0 + ts; s0 = s0 + sh; s1 = s1 + sh; s2 = s2 + sh; s3 = s3 + sh; }
+  nrm = sqrt(mm_qp_dot(z0, z0, z1, z1, z2, z2, z3, z3, m4));
+  const double tz = mm_qp_maxneg(z0, z1, z2, z3, m4);
+  if (tz >= -1e-8 * fmax(nrm, 1.0)) { const double sh = 1.0 + tz; z0 = z0 + sh; z1 = z1 + sh; z2 = z2 + sh; z3 = z3 + sh; }
   q->x0 = x0; q->x2 = x2;
-  q->gap = mm_qp_dot(s, z, m4);
-  for (int k = 0; k < 4; k++) { q->d[k] = 1.0; q->di[k] = 1.0; q->lmbda[k] = 1.0; }
+  q->s0 = s0; q->s1 = s1; q->s2 = s2; q->s3 = s3; q->z0 = z0; q->z1 = z1; q->z2 = z2; q->z3 = z3;
+  q->gap = mm_qp_dot(s0, z0, s1, z1, s2, z2, s3, z3, m4);
   return 1;
 }
 
 /* Residuals of the current iterate and cvxopt's stopping test.  Returns 0: go on (call mm_qp_bottom with *r), 1: stop,
- * "optimal", 2: stop, "unknown" (iteration cap).  m4 is passed so that a caller with a compile-time value gets the
- * specialised code. */
-MMM_FN int mm_qp_top(const MMQpState *q, int m4, MMQpRes *r) {
+ * "optimal", 2: stop, "unknown" (iteration cap). */
+MMM_FN int mm_qp_top(const MMQpState *q, MMQpRes *r) {
+  const int m4 = q->m4;
   const double a = q->a, x0 = q->x0, x2 = q->x2, gap = q->gap;
-  const double *s = q->s, *z = q->z, *h = q->h;
   /* rx = P x + G' z ; f0 = 1/2 x'Px ; rz = s + G x - h */
   double rx0 = 0.0 + 1.0 * x0, rx2 = 0.0 + 1e18 * x2;
   const double f0 = 0.5 * (((0.0 + x0 * rx0) + x2 * rx2) + 0.0);
-  double t = 0.0 + a * z[0];
-  t = t + 1.0 * z[1];
-  t = t + (-1.0) * z[2];
-  if (m4) t = t + a * z[3];
+  double t = 0.0 + a * q->z0;
+  t = t + 1.0 * q->z1;
+  t = t + (-1.0) * q->z2;
+  double u = 0.0 + (-1.0) * q->z0;
+  const double rz0 = ((q->s0 - q->h0) + x0 * a) + x2 * (-1.0);
+  const double rz1 = (q->s1 - q->h1) + x0 * 1.0;
+  const double rz2 = (q->s2 - q->h2) + x0 * (-1.0);
+  double rz3 = 0.0;
+  if (m4) {
+    t = t + a * q->z3;
+    u = u + (-1.0) * q->z3;
+    rz3 = ((q->s3 - q->h3) + x0 * a) + x2 * (-1.0);
+  }
   rx0 = rx0 + t;
-  t = 0.0 + (-1.0) * z[0];
-  if (m4) t = t + (-1.0) * z[3];
-  rx2 = rx2 + t;
+  rx2 = rx2 + u;
   const double resx = sqrt((0.0 + rx0 * rx0) + rx2 * rx2);
-  double *rz = r->rz;
-  rz[0] = ((s[0] - h[0]) + x0 * a) + x2 * (-1.0);
-  rz[1] = (s[1] - h[1]) + x0 * 1.0;
-  rz[2] = (s[2] - h[2]) + x0 * (-1.0);
-  rz[3] = m4 ? ((s[3] - h[3]) + x0 * a) + x2 * (-1.0) : 0.0;
-  r->rx0 = rx0; r->rx2 = rx2;
-  const double resz = sqrt(mm_qp_dot(rz, rz, m4));
-  const double pcost = f0, dcost = f0 + mm_qp_dot(z, rz, m4) - gap;
+  r->rx0 = rx0; r->rx2 = rx2; r->rz0 = rz0; r->rz1 = rz1; r->rz2 = rz2; r->rz3 = rz3;
+  const double resz = sqrt(mm_qp_dot(rz0, rz0, rz1, rz1, rz2, rz2, rz3, rz3, m4));
+  const double pcost = f0, dcost = f0 + mm_qp_dot(q->z0, rz0, q->z1, rz1, q->z2, rz2, q->z3, rz3, m4) - gap;
   int have_rel = 0;
   double relgap = 0.0;
   if (pcost < 0.0) { relgap = gap / -pcost; have_rel = 1; }
@@ -192,64 +212,85 @@ MMM_FN int mm_qp_top(const MMQpState *q, int m4, MMQpRes *r) {
   return met ? 1 : 0;
 }
 
+/* the predictor (I = 0) or corrector (I = 1) solve of one iteration: right-hand side, KKT solve, scaled steps, max step */
+#define MM_QP_PASS(I)                                                                                              \
+  {                                                                                                                \
+    double t0_ = 0.0, t1_ = 0.0, t2_ = 0.0, t3_ = 0.0;                                                             \
+    if (I == 1) { t0_ = t0_ - ws0; t1_ = t1_ - ws1; t2_ = t2_ - ws2; }                                             \
+    t0_ = t0_ - lsq0; t1_ = t1_ - lsq1; t2_ = t2_ - lsq2;                                                          \
+    ds0 = t0_ + sigma * mu; ds1 = t1_ + sigma * mu; ds2 = t2_ + sigma * mu;                                        \
+    dx0 = -r->rx0; dx2 = -r->rx2;                                                                                  \
+    ds0 = MM_QP_DIVR(ds0, q->l0, rl0); ds1 = MM_QP_DIVR(ds1, q->l1, rl1); ds2 = MM_QP_DIVR(ds2, q->l2, rl2);       \
+    dz0 = -r->rz0 - q->d0 * ds0; dz1 = -r->rz1 - q->d1 * ds1; dz2 = -r->rz2 - q->d2 * ds2;                         \
+    if (m4) {                                                                                                      \
+      if (I == 1) t3_ = t3_ - ws3;                                                                                 \
+      t3_ = t3_ - lsq3;                                                                                            \
+      ds3 = t3_ + sigma * mu;                                                                                      \
+      ds3 = MM_QP_DIVR(ds3, q->l3, rl3);                                                                           \
+      dz3 = -r->rz3 - q->d3 * ds3;                                                                                 \
+    }                                                                                                              \
+    mm_qp_solve(&kkt, m4, &dx0, &dx2, &dz0, &dz1, &dz2, &dz3);                                                     \
+    ds0 = ds0 - dz0; ds1 = ds1 - dz1; ds2 = ds2 - dz2;                                                             \
+    if (m4) ds3 = ds3 - dz3;                                                                                       \
+    dsdz = mm_qp_dot(ds0, dz0, ds1, dz1, ds2, dz2, ds3, dz3, m4);                                                  \
+    if (I == 0) { ws0 = ds0 * dz0; ws1 = ds1 * dz1; ws2 = ds2 * dz2; if (m4) ws3 = ds3 * dz3; }                    \
+    ds0 = MM_QP_DIVR(ds0, q->l0, rl0); dz0 = MM_QP_DIVR(dz0, q->l0, rl0);                                          \
+    ds1 = MM_QP_DIVR(ds1, q->l1, rl1); dz1 = MM_QP_DIVR(dz1, q->l1, rl1);                                          \
+    ds2 = MM_QP_DIVR(ds2, q->l2, rl2); dz2 = MM_QP_DIVR(dz2, q->l2, rl2);                                          \
+    if (m4) { ds3 = MM_QP_DIVR(ds3, q->l3, rl3); dz3 = MM_QP_DIVR(dz3, q->l3, rl3); }                              \
+    const double ts_ = mm_qp_maxneg(ds0, ds1, ds2, ds3, m4), tz_ = mm_qp_maxneg(dz0, dz1, dz2, dz3, m4);           \
+    const double tm_ = fmax(0.0, fmax(ts_, tz_));                                                                  \
+    if (tm_ == 0) step = 1.0;                                                                                      \
+    else if (I == 0) step = fmin(1.0, MM_QP_DIV(1.0, tm_));                                                        \
+    else step = fmin(1.0, MM_QP_DIV(MM_QP_STEP, tm_));                                                             \
+  }
+/* misc.update_scaling for row K: the updated iterates in the current scaling, then the new scaling */
+#define MM_QP_UPDATE(K)                                                                                            \
+  {                                                                                                                \
+    double us_ = (step * ds##K + 1.0) * q->l##K, uz_ = (step * dz##K + 1.0) * q->l##K;                            \
+    us_ = MM_QP_SQRT(us_);                                                                                         \
+    uz_ = MM_QP_SQRT(uz_);                                                                                         \
+    q->d##K = MM_QP_DIV(q->d##K * us_, uz_);                                                                       \
+    q->di##K = MM_QP_DIV(1.0, q->d##K);                                                                            \
+    q->l##K = us_ * uz_;                                                                                           \
+    q->s##K = q->d##K * q->l##K;                                                                                   \
+    q->z##K = q->di##K * q->l##K;                                                                                  \
+  }
+/* misc.compute_scaling for row K (first iteration) */
+#define MM_QP_SCALE0(K)                                                                                            \
+  { q->d##K = MM_QP_SQRT(MM_QP_DIV(q->s##K, q->z##K)); q->di##K = MM_QP_DIV(1.0, q->d##K); q->l##K = MM_QP_SQRT(q->s##K * q->z##K); }
+
 /* One interior-point iteration from the residuals of mm_qp_top.  Returns 0 when the KKT matrix is singular ("Terminated
  * (singular KKT matrix)": the iterate stands, status "unknown"), else 1. */
-MMM_FN int mm_qp_bottom(MMQpState *q, int m4, const MMQpRes *r) {
+MMM_FN int mm_qp_bottom(MMQpState *q, const MMQpRes *r) {
+  const int m4 = q->m4;
   const double a = q->a, mm = m4 ? 4.0 : 3.0, gap = q->gap;
-  double *s = q->s, *z = q->z, *d = q->d, *di = q->di, *lmbda = q->lmbda;
-  const double *rz = r->rz;
-  double lmbdasq[4], dz[4], ds[4], ws3[4] = {0.0, 0.0, 0.0, 0.0}, rl[4];
+  if (q->iters == 0) {
+    MM_QP_SCALE0(0) MM_QP_SCALE0(1) MM_QP_SCALE0(2)
+    if (m4) MM_QP_SCALE0(3)
+  }
+  const double lsq0 = q->l0 * q->l0, lsq1 = q->l1 * q->l1, lsq2 = q->l2 * q->l2;
+  const double rl0 = MM_QP_RCP(q->l0), rl1 = MM_QP_RCP(q->l1), rl2 = MM_QP_RCP(q->l2);
+  double lsq3 = 1.0, rl3 = 1.0;
+  if (m4) { lsq3 = q->l3 * q->l3; rl3 = MM_QP_RCP(q->l3); }
+  (void)rl0; (void)rl1; (void)rl2; (void)rl3;
   MMQpKkt kkt;
-  double t;
-  if (q->iters == 0) {  /* misc.compute_scaling */
-    for (int k = 0; k < 4; k++)
-      if (k < 3 || m4) { d[k] = sqrt(s[k] / z[k]); di[k] = 1.0 / d[k]; lmbda[k] = sqrt(s[k] * z[k]); }
-      else { d[k] = 1.0; di[k] = 1.0; lmbda[k] = 1.0; }
-  }
-  for (int k = 0; k < 4; k++) { lmbdasq[k] = lmbda[k] * lmbda[k]; rl[k] = MM_QP_RCP(lmbda[k]); }
-  (void)rl;
-  if (!mm_qp_factor(&kkt, a, m4, di)) return 0;
+  if (!mm_qp_factor(&kkt, a, m4, q->di0, q->di1, q->di2, q->di3)) return 0;
   const double mu = gap / mm;
-  double sigma = 0.0, step = 1.0, dx0 = 0.0, dx2 = 0.0;
-  for (int i = 0; i < 2; i++) {
-    for (int k = 0; k < 4; k++) {
-      t = 0.0;
-      if (i == 1) t = t - ws3[k];
-      t = t - lmbdasq[k];
-      ds[k] = t + sigma * mu;
-    }
-    dx0 = -r->rx0; dx2 = -r->rx2;
-    for (int k = 0; k < 4; k++) { dz[k] = -rz[k]; ds[k] = MM_QP_DIVR(ds[k], lmbda[k], rl[k]); dz[k] = dz[k] - d[k] * ds[k]; }
-    mm_qp_solve(&kkt, m4, &dx0, &dx2, dz);
-    for (int k = 0; k < 4; k++) ds[k] = ds[k] - dz[k];
-    const double dsdz = mm_qp_dot(ds, dz, m4);
-    if (i == 0) for (int k = 0; k < 4; k++) ws3[k] = ds[k] * dz[k];
-    for (int k = 0; k < 4; k++) { ds[k] = MM_QP_DIVR(ds[k], lmbda[k], rl[k]); dz[k] = MM_QP_DIVR(dz[k], lmbda[k], rl[k]); }
-    const double ts = mm_qp_maxneg(ds, m4), tz = mm_qp_maxneg(dz, m4);
-    const double tm = fmax(0.0, fmax(ts, tz));
-    if (tm == 0) step = 1.0;
-    else if (i == 0) step = fmin(1.0, 1.0 / tm);
-    else step = fmin(1.0, MM_QP_STEP / tm);
-    if (i == 0) {
-      const double sg = fmin(1.0, fmax(0.0, 1.0 - step + dsdz / gap * (step * step)));
-      sigma = sg * sg * sg;
-    }
+  double sigma = 0.0, step = 1.0, dx0 = 0.0, dx2 = 0.0, dsdz = 0.0;
+  double ds0 = 0.0, ds1 = 0.0, ds2 = 0.0, ds3 = 0.0, dz0 = 0.0, dz1 = 0.0, dz2 = 0.0, dz3 = 0.0;
+  double ws0 = 0.0, ws1 = 0.0, ws2 = 0.0, ws3 = 0.0;
+  MM_QP_PASS(0)
+  {
+    const double sg = fmin(1.0, fmax(0.0, 1.0 - step + MM_QP_DIV(dsdz, gap) * (step * step)));
+    sigma = sg * sg * sg;
   }
+  MM_QP_PASS(1)
   q->x0 = q->x0 + step * dx0;
   q->x2 = q->x2 + step * dx2;
-  for (int k = 0; k < 4; k++) {  /* updated iterates in the current scaling, then misc.update_scaling */
-    if (k == 3 && !m4) continue;
-    ds[k] = (step * ds[k] + 1.0) * lmbda[k];
-    dz[k] = (step * dz[k] + 1.0) * lmbda[k];
-    ds[k] = sqrt(ds[k]);
-    dz[k] = sqrt(dz[k]);
-    d[k] = d[k] * ds[k] / dz[k];
-    di[k] = 1.0 / d[k];
-    lmbda[k] = ds[k] * dz[k];
-    s[k] = d[k] * lmbda[k];
-    z[k] = di[k] * lmbda[k];
-  }
-  q->gap = mm_qp_dot(lmbda, lmbda, m4);
+  MM_QP_UPDATE(0) MM_QP_UPDATE(1) MM_QP_UPDATE(2)
+  if (m4) MM_QP_UPDATE(3)
+  q->gap = mm_qp_dot(q->l0, q->l0, q->l1, q->l1, q->l2, q->l2, q->l3, q->l3, m4);
   q->iters = q->iters + 1;
   return 1;
 }
@@ -263,9 +304,9 @@ MMM_FN int mm_qp_ipm_cbf(double a, double h0, double h1, double h2, double h3, i
   int status = 0;
   if (mm_qp_start(&q, a, h0, h1, h2, h3, rows)) {
     for (;;) {
-      const int stop = mm_qp_top(&q, q.m4, &r);
+      const int stop = mm_qp_top(&q, &r);
       if (stop) { status = stop == 1; break; }
-      if (!mm_qp_bottom(&q, q.m4, &r)) break;
+      if (!mm_qp_bottom(&q, &r)) break;
     }
   }
   *d_out = q.x0; *s_out = q.x2; *iters_out = q.iters;

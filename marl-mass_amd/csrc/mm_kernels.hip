@@ -43,6 +43,7 @@ struct DevCfg {
 #define MM_LATCH_QP_BOUNDS 1  // CBFType.check_bounds, cbf.py:87-96
 #define MM_LATCH_BAD_ACTION 2 // DiscreteMetaAction.act: self.actions[action] KeyError, action.py:194-196
 #define MM_LATCH_BAD_QP 4     // mm_shield_qp: G is not of the form get_G builds
+#define MM_LATCH_INTERNAL 8   // a loop guard of the kernels fired (never expected; reported as MM_ERR_DEVICE)
 struct DevState {
   double *F;
   uint8_t *B;
@@ -698,60 +699,59 @@ MM_DEV double slot_gu(double vx, double acc, double g, double dt) {
   u = u > 0 ? u : 0;
   return (MASS ? g * dt : 1 * dt) * u;
 }
+// The CBF rows of the QP that depend on the neighbours' decided accelerations: h0 (leader), h3 (front-adjacent, MASS with
+// constrain_adj) and the two g*u products they are built from.
 // PRE: nb.ol_gu / nb.oa_gu already hold those products (computed by the lanes that own the records)
-// IPM: solve the QP by cvxopt's interior-point algorithm (MM_QP_IPM); `run_qp` = this lane's result is wanted (the
-// literal sweep evaluates every lane at every stage and keeps the ego's only: the others must not iterate on garbage)
-template <bool MASS, bool PRE = false, bool IPM = false>
-MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s, const Neigh &nb, bool run_qp = true) {
-  const double dt = c.dt, eta = c.eta;
-  ShieldOut o;
-  double g2u2, g4u4;
+struct ShieldRows { double g2u2, g4u4, h0, h3; };
+template <bool PRE>
+MM_DEV ShieldRows shield_rows(const DevCfg &c, const ShieldStatic &s, const Neigh &nb) {
+  const double dt = c.dt;
+  ShieldRows r;
   if (PRE) {
-    g2u2 = nb.has_ol ? nb.ol_gu : 0.0;
-    g4u4 = nb.has_oa ? nb.oa_gu : 0.0;
+    r.g2u2 = nb.has_ol ? nb.ol_gu : 0.0;
+    r.g4u4 = nb.has_oa ? nb.oa_gu : 0.0;
   } else {
     double u2 = 0, u4 = 0;
     if (nb.has_ol) { u2 = nb.ol_vx + nb.ol_acc * dt; u2 = u2 > 0 ? u2 : 0; }
     if (nb.has_oa) { u4 = nb.oa_vx + nb.oa_acc * dt; u4 = u4 > 0 ? u4 : 0; }
-    g2u2 = s.g2 * u2;
-    g4u4 = s.g4 * u4;
+    r.g2u2 = s.g2 * u2;
+    r.g4u4 = s.g4 * u4;
   }
   const double g0u0 = s.g0 * s.u0;
-  const double h0 = s.base0 + (-g0u0 + g2u2);
-  double h3 = __builtin_nan(""), hc = h0;
-  if (s.cadj) {
-    h3 = s.base3 + (-g0u0 + g4u4);
-    hc = h3 < h0 ? h3 : h0;
-  }
+  r.h0 = s.base0 + (-g0u0 + r.g2u2);
+  r.h3 = __builtin_nan("");
+  if (s.cadj) r.h3 = s.base3 + (-g0u0 + r.g4u4);
+  return r;
+}
+// exact KKT point of min 1/2(d^2 + e^2 + 1e18 s^2) s.t. a d - s <= hc, lo <= d <= hi.  (d is clipped into
+// [v_min - u0, v_max - u0] and v_min <= v_max, so check_bounds cannot fire in this mode.)
+MM_DEV double qp_exact(const ShieldStatic &s, const ShieldRows &r) {
+  const double hc = (s.cadj && r.h3 < r.h0) ? r.h3 : r.h0;
   double d;
-  o.optimal = true; o.bounds = false;
-  if constexpr (IPM) {
-    // the iterate cvxopt.solvers.qp stops at (cbf.py:134), its status (:140) and check_bounds (:87-96)
-    d = 0.0;
-    if (run_qp) {
-      double slack;
-      int iters;
-      o.optimal = mm_qp_ipm_cbf(s.g0, h0, s.h1, s.h2, h3, s.cadj ? 4 : 3, &d, &slack, &iters) != 0;
-      o.bounds = (s.u0 + d) - 0.001 > s.v_max || (s.u0 + d) + 0.001 < s.v_min;
-    }
-  } else {
-    // exact KKT point of min 1/2(d^2 + e^2 + 1e18 s^2) s.t. a d - s <= hc, lo <= d <= hi.  (d is clipped into
-    // [v_min - u0, v_max - u0] and v_min <= v_max, so check_bounds cannot fire in this mode.)
-    if (s.g0 > 0) d = fmin(0.0, hc / s.g0);
-    else if (s.g0 < 0) d = fmax(0.0, hc / s.g0);
-    else d = 0.0;
-    d = fmin(fmax(d, -s.h2), s.h1);
-  }
+  if (s.g0 > 0) d = fmin(0.0, hc / s.g0);
+  else if (s.g0 < 0) d = fmax(0.0, hc / s.g0);
+  else d = 0.0;
+  return fmin(fmax(d, -s.h2), s.h1);
+}
+// Everything after the QP returned d (cbf.py:134-161, decentral_layer.py:493-518 / :721-764): status, is_lc_allowed, the
+// veto, the collaboration flags and the derived acceleration.  `optimal`: sol["status"] != "unknown"; `check`: evaluate
+// check_bounds (only the interior-point iterate can leave the bounds)
+template <bool MASS>
+MM_DEV ShieldOut shield_post(const DevCfg &c, const Veh &v, const ShieldStatic &s, const ShieldRows &r, double d, bool optimal, bool check) {
+  const double dt = c.dt, eta = c.eta;
+  ShieldOut o;
+  o.optimal = optimal;
+  o.bounds = check && ((s.u0 + d) - 0.001 > s.v_max || (s.u0 + d) + 0.001 < s.v_min);
   double us0 = s.u0 + d;
   {  // update_status (cbf.py:341-351) on u_status = [u_safe (QP), u_ll[2:]]
     const double hls_lon = s.px_lon + s.q_lon;
-    const double hlds_lon = s.px_lon + ((-s.g0) * us0 + g2u2) + s.q_lon;
+    const double hlds_lon = s.px_lon + ((-s.g0) * us0 + r.g2u2) + s.q_lon;
     o.lon_safe = hls_lon >= -1e-6;
     o.lon_invariant = (hlds_lon + (eta - 1) * hls_lon) >= -1e-6;
     o.hw_num = s.px_lon - kVehLength; o.hw_den = s.evx;
   }
   // is_lc_allowed (cbf.py:324-339)
-  const double hlds_lona = s.px_lona + ((-s.g0) * us0 + g4u4) + s.q_lona;
+  const double hlds_lona = s.px_lona + ((-s.g0) * us0 + r.g4u4) + s.q_lona;
   const double hlds_lonr = s.px_lonr + (s.g0 * us0 + (-s.g6) * s.u6) + s.q_lonr;
   const double inv_lona = hlds_lona + (eta - 1) * s.hls_lona, inv_lonr = hlds_lonr + (eta - 1) * s.hls_lonr;
   const bool lc_allowed = ((s.hls_lona >= 0) && inv_lona >= 0) && ((s.hls_lonr >= 0) && inv_lonr >= 0);
@@ -769,9 +769,31 @@ MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s
   if (!veto) fl |= MM_FLAG_IS_LC_SAFE;
   o.acc = div_c(us0 - s.evx, dt, c.inv_dt);  // derived_acceleration :80-82
   o.us0 = us0; o.veto = veto; o.flags = fl;
-  o.qt.rows = s.cadj ? 4 : 3; o.qt.a = s.g0; o.qt.h0 = h0; o.qt.h1 = s.h1; o.qt.h2 = s.h2; o.qt.h3 = h3; o.qt.d = d;
+  o.qt.rows = s.cadj ? 4 : 3; o.qt.a = s.g0; o.qt.h0 = r.h0; o.qt.h1 = s.h1; o.qt.h2 = s.h2; o.qt.h3 = r.h3; o.qt.d = d;
   o.qt.margin = fmin(fmin(s.hls_lona, inv_lona), fmin(s.hls_lonr, inv_lonr));
   return o;
+}
+// IPM: solve the QP by cvxopt's interior-point algorithm (MM_QP_IPM), here as ONE start-to-stop solve of this lane's QP
+// (literal sweep, stand-alone shield kernel; the parallel form of the step kernel runs the wave-wide loop instead);
+// `run_qp` = this lane's result is wanted (the literal sweep evaluates every lane at every stage and keeps the ego's
+// only: the others must not iterate on garbage)
+template <bool MASS, bool PRE = false, bool IPM = false>
+MM_DEV ShieldOut shield_dyn(const DevCfg &c, const Veh &v, const ShieldStatic &s, const Neigh &nb, bool run_qp = true) {
+  const ShieldRows r = shield_rows<PRE>(c, s, nb);
+  double d;
+  bool optimal = true;
+  if constexpr (IPM) {
+    // the iterate cvxopt.solvers.qp stops at (cbf.py:134), its status (:140) and check_bounds (:87-96)
+    d = 0.0;
+    if (run_qp) {
+      double slack;
+      int iters;
+      optimal = mm_qp_ipm_cbf(s.g0, r.h0, s.h1, s.h2, r.h3, s.cadj ? 4 : 3, &d, &slack, &iters) != 0;
+    }
+  } else {
+    d = qp_exact(s, r);
+  }
+  return shield_post<MASS>(c, v, s, r, d, optimal, IPM && run_qp);
 }
 template <bool MASS, bool PRE = false, bool IPM = false>
 MM_DEV ShieldOut shield_eval(const DevCfg &c, const Veh &v, double cpsi, int pk_self, const Neigh &nb, bool run_qp = true) {
@@ -869,9 +891,8 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
 #ifdef MM_SERIAL_MASS  // tuning switch: MASS in the literal form at every size
   constexpr bool kSerialOnly = MIXED || MASS || IPM;
 #else
-  // (IPM + MASS: a follower's QP reads its leader's DECIDED acceleration bit for bit, so every round of the fixed point would
-  // be a full interior-point solve on all lanes -- the literal sweep is cheaper; IPM + HSS has no such coupling)
-  constexpr bool kSerialOnly = MIXED || (IPM && MASS);
+  // (IPM: the parallel form runs the dependency-driven wave-wide interior-point loop below instead of the rounds)
+  constexpr bool kSerialOnly = MIXED;
 #endif
 #endif
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1131,6 +1152,11 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
         // test st.N > 6 as well cost them 3 % through 20 B/lane more scratch)
         constexpr bool count5 = G > 4;
         if constexpr (kMailbox) { s_cold[C_PRE + 0][tid] = v.x; s_cold[C_PRE + 1][tid] = v.y; s_cold[C_PRE + 2][tid] = v.h; cold_i(C_PRE + 3, tid) = pk_self; }
+        // (interior-point mode) the QP this lane solved in the previous veto pass of this sub-step: rows that did not change
+        // need no second solve.  a, h1, h2 depend on the lane's own pre-step state only, so (rows, h0, h3) identify the QP.
+        double qc_h0 = 0.0, qc_h3 = 0.0, qc_d = 0.0;
+        int qc_meta = 0;  // rows (3 | 4; 0: nothing cached) | 8: status "optimal"
+        (void)qc_h0; (void)qc_h3; (void)qc_d; (void)qc_meta;
         for (int pass = 0; pass <= st.N; pass++) {
           const double mine_gvx = s_cold[(use_B ? C_B : C_A) + 6][tid];  // g.vx of the candidate I commit
           const double h1vx_mine = s_cold[C_H1VX][tid];
@@ -1236,6 +1262,78 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
           double acc_cur = shield_on ? 0.0 : v.act_acc;  // vehicles without a shield keep their command
           if constexpr (kRoomy) v.gvx = GVX();
           const ShieldStatic ss = shield_static<MASS>(c, v, cpsi_now, pk_self, nb);
+          if constexpr (IPM) {
+            // ---- interior-point mode: ONE wave-wide loop, every lane at its own iteration of its own QP ----------------
+            // A follower's QP reads the acceleration its leader / front-adjacent vehicle DECIDED this sub-step, so a QP can
+            // start only when those decisions are final (`fin`).  Each trip of the loop: (1) every running lane evaluates
+            // cvxopt's stopping test (mm_qp_top); a lane that stops derives its acceleration and becomes final; (2) lanes
+            // whose inputs are final now -- including the ones that became final in (1) -- set up their rows and start
+            // (mm_qp_start + the stopping test of the initial point), or take the answer of the previous veto pass when the
+            // rows did not change; (3) every running lane does one interior-point iteration (mm_qp_bottom).  A QP with n
+            // iterations occupies n trips and its follower starts in the trip it stopped in, so the wave leaves after its
+            // longest dependency chain of iterations -- not after N sweep stages, and a QP that runs to the iteration cap
+            // holds up its own followers only.  tools/ipm_sched_model.py replays this schedule on the CPU oracle's QP log.
+            // Only what the loop itself reads stays live in it: the rows' ingredients and, per finished lane, the decided
+            // acceleration its followers wait for; status / veto / flags are evaluated once after the loop (shield_post).
+            bool fin = !shield_on, run = false, sing = false;
+            bool late = false, late_opt = false;  // finished outside step (1): posted in the next trip
+            const bool slow_lc = MASS && (v.hl == 2 || v.hl == 0) && v.v < kStoppingSpeed;  // decentral_layer.py:746-750: the decision needs the veto
+            MMQpState q;
+            q.x0 = 0.0; q.m4 = 0; q.iters = 0;
+            bool more = true;  // wave-uniform
+            for (int trip = 0; more; trip++) {
+              if (trip > (MM_QP_MAXITERS + 2) * (G + 1)) { atomicOr(c.err, MM_LATCH_INTERNAL); break; }  // cannot happen: every trip starts or advances a QP
+              MMQpRes rs;
+              bool done_now = late, opt = late_opt;
+              late = false;
+              if (run) {
+                const int stop = mm_qp_top(&q, &rs);
+                if (stop || sing) { run = false; done_now = true; opt = stop == 1 && !sing; }
+              }
+              if (__any(done_now)) {
+                if (done_now) {
+                  double us0 = ss.u0 + q.x0;
+                  if (MASS && slow_lc) us0 = shield_post<MASS>(c, v, ss, shield_rows<true>(c, ss, nb), q.x0, opt, true).us0;
+                  acc_cur = div_c(us0 - ss.evx, dt, c.inv_dt);  // derived_acceleration :80-82 (== shield_post's)
+                  fin = true;
+                  qc_d = q.x0; qc_meta = (ss.cadj ? 4 : 3) | (opt ? 8 : 0);
+                }
+              }
+              bool ready = shield_on && !fin && !run;
+              double da = 0.0, db = 0.0;
+              if (MASS) {
+                const double gu_cur = slot_gu<true>(h1vx_mine, acc_cur, mine_gvx, dt);  // my post-step record under my decision
+                da = shfl_d(gu_cur, src_ol); db = shfl_d(gu_cur, src_oa);
+                const unsigned long long fm = __ballot(fin);
+                ready = ready && (!ol_dyn || ((fm >> src_ol) & 1ull)) && (!oa_dyn || ((fm >> src_oa) & 1ull));
+              }
+              if (__any(ready)) {
+                if (ready) {
+                  if (MASS) { if (ol_dyn) nb.ol_gu = da; if (oa_dyn) nb.oa_gu = db; }
+                  const ShieldRows rw = shield_rows<true>(c, ss, nb);
+                  const int rows = ss.cadj ? 4 : 3;
+                  if ((qc_meta & 7) == rows && __double_as_longlong(qc_h0) == __double_as_longlong(rw.h0) &&
+                      __double_as_longlong(qc_h3) == __double_as_longlong(rw.h3)) {
+                    q.x0 = qc_d; late = true; late_opt = (qc_meta & 8) != 0;  // same QP as in the previous pass: same answer
+                  } else {
+                    qc_h0 = rw.h0; qc_h3 = rw.h3;
+                    sing = false;
+                    // (a singular initial KKT system -- NaN input -- makes cvxopt raise: iterate NaN, "unknown")
+                    int stop = mm_qp_start(&q, ss.g0, rw.h0, ss.h1, ss.h2, rw.h3, rows) != 0 ? 0 : 2;
+                    if (!stop) stop = mm_qp_top(&q, &rs);
+                    run = stop == 0;
+                    if (stop) { late = true; late_opt = stop == 1; }
+                  }
+                }
+              }
+              const bool any_run = __any(run);
+              if (any_run) {
+                if (run) sing = mm_qp_bottom(&q, &rs) == 0;  // singular KKT matrix: the iterate stands, status "unknown"
+              }
+              more = any_run || __any(!fin);  // (nothing iterating but lanes not final: they waited for this trip's decisions)
+            }
+            if (shield_on) so = shield_post<MASS>(c, v, ss, shield_rows<true>(c, ss, nb), qc_d, (qc_meta & 8) != 0, true);
+          } else {
           for (int round = 0; round <= st.N; round++) {
             if (MASS) {
               const double gu_cur = slot_gu<true>(h1vx_mine, acc_cur, mine_gvx, dt);  // my post-step record under my current decision
@@ -1243,11 +1341,12 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
               if (ol_dyn) nb.ol_gu = da;
               if (oa_dyn) nb.oa_gu = db;
             }
-            so = shield_dyn<MASS, true, IPM>(c, v, ss, nb, shield_on);
+            so = shield_dyn<MASS, true, false>(c, v, ss, nb, shield_on);
             const double acc_next = shield_on ? so.acc : v.act_acc;
             const bool changed = __double_as_longlong(acc_next) != __double_as_longlong(acc_cur);
             acc_cur = acc_next;
             if (!MASS || !__any(changed)) break;
+          }
           }
           if (TRACE && shield_on) trace_status(out.trace + (long long)k * MM_T_COUNT * A + i, A, so);
           STAMP(4);  // selection + fixed-point rounds
@@ -2022,6 +2121,7 @@ extern "C" int32_t mm_poll_errors(MMHandle h, MMStream stream) {
   if (bits & MM_LATCH_QP_BOUNDS) { snprintf(h->err, sizeof h->err, "Error in QP. Invalid accceleration"); return MM_ERR_QP_BOUNDS; }
   if (bits & MM_LATCH_BAD_ACTION) { snprintf(h->err, sizeof h->err, "an action is outside 0..4"); return MM_ERR_INVALID_ARG; }
   if (bits & MM_LATCH_BAD_QP) { snprintf(h->err, sizeof h->err, "mm_shield_qp: G is not of the form get_G builds (cbf.py:288-304,386-403)"); return MM_ERR_INVALID_ARG; }
+  if (bits & MM_LATCH_INTERNAL) { snprintf(h->err, sizeof h->err, "internal: a kernel loop guard fired"); return MM_ERR_DEVICE; }
   return MM_OK;
 }
 extern "C" int32_t mm_set_config(MMHandle h, const MMConfig *cfg) {
@@ -2197,7 +2297,11 @@ void mm_launch_step_ipm(MMHandle h, const int32_t *actions, const MMStepOut *out
 template <int G>
 static void launch_step_g(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
 #ifdef MM_ONLY_MIXED  // tuning builds
+#ifdef MM_ONLY_IPM
+  launch_step_t<G, MM_ENV_V1, MM_ONLY_SHIELD, MM_ONLY_MIXED, true>(h, actions, out, s);
+#else
   launch_step_m<G, MM_ONLY_MIXED>(h, actions, out, s);
+#endif
 #else
   const bool shielded = h->cfg.env_kind == MM_ENV_V1 && h->cfg.shield != MM_SHIELD_NONE;
   if (shielded && h->cfg.qp_solver == MM_QP_IPM)

@@ -10,12 +10,12 @@ env_id, safety, N, E, steps, eta, tau = sys.argv[1], sys.argv[2], int(sys.argv[3
 n_hdv = int(sys.argv[8]) if len(sys.argv) > 8 else 0
 oracle_env.set_math_mode(1)
 kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau}, cbf_eta=eta, cbf_tau=tau,
-          obs_f64=True, seed=1000, auto_reset=True, trace=True, n_hdv=n_hdv)
+          obs_f64=True, seed=1000, auto_reset=True, trace=True, n_hdv=n_hdv, qp_solver=os.environ.get("MM_QP_SOLVER", "exact"))
 import os
 gpu, cpu = VecMergeEnv(E, N, device="cuda:0", debug_flags=int(os.environ.get("MM_DEBUG_FLAGS", "0")), **kw), oracle_env.OracleEnv(E, N, **kw)
 gpu.reset(); cpu.reset()
 g = torch.Generator().manual_seed(123)
-p = torch.tensor([0.1, 0.6, 0.1, 0.1, 0.1])
+p = torch.tensor([float(x) for x in os.environ.get("MM_ACTION_P", "0.1,0.6,0.1,0.1,0.1").split(",")])
 for t in range(steps):
     a = torch.multinomial(p, E * N, True, generator=g).view(E, N).int()
     sg, sc = gpu.f64.cpu().clone(), cpu.f64.clone()
