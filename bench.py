@@ -12,10 +12,11 @@ so ranks shard the batch with no data-path collective; the only RCCL traffic is 
 all-reduce after the timed region.
 
 Scaling modes (the line says which one ran, in `scaling`, `metric` and `config.workload`):
-  --scaling weak   (default) every rank holds --envs (65 536) envs: BASELINE's metric config on ONE GPU,
-                   replicated per GPU -- per-GPU work fixed as N grows;
-  --scaling strong --total-envs (65 536) envs are split over the ranks: at 8 ranks this is BASELINE.json
-                   config 5 exactly (8 192 envs per GPU) -- total work fixed.
+  --scaling strong (default) --total-envs (65 536) envs are split over the ranks: BASELINE.json's metric on its own
+                   configuration at every N -- one GPU holds the whole batch, 8 ranks are config 5 exactly (8 192 envs
+                   per GPU); total work fixed.  With N > 1 the line also carries `weak_scaling`: the same kernel with
+                   --envs (65 536) envs on EVERY rank, timed right after the headline region;
+  --scaling weak   every rank holds --envs (65 536) envs (BASELINE's batch replicated per GPU) as the headline value.
 
 The batch is made STATIONARY before anything is timed: episode phases are staggered over the batch
 (env e starts at step (37 e) mod 100) and one untimed episode length is rolled, so every timed window --
@@ -34,6 +35,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+QP_MODE_NOTE = {"exact": "closed-form KKT point of the shield QP: outside north_star's 1e-5 against the reference's interior-point "
+                         "iterate, see config.tolerance",
+                "ipm": "cvxopt's interior-point iterate, the reference's own solver behaviour: inside north_star's 1e-5"}
 SHIELDS = {"mass": "cbf-cav", "hss": "cbf-avs_cint", "none": "none"}
 
 
@@ -100,10 +104,12 @@ def cpu_baseline(args, env_id, cfg, kw):
     return out
 
 
-def fidelity_mode_rate(args, dev, E, N, cfg, kw, ring, steps=12):
-    """The headline workload once more with qp_solver="ipm" (every QP through the interior-point iteration the
-    reference's cvxopt call runs, bit-identical to the reference-side restatement): same stationary batch, a short
-    timed window -- it is ~20x slower than the exact mode and only reported."""
+def ipm_mode_line(args, dev, E, N, cfg, kw, ring, steps=12):
+    """The headline workload once more with qp_solver="ipm": every shield QP through the interior-point iteration the
+    reference's cvxopt call runs (bit-identical to the reference-side restatement of coneqp), same stationary batch, a short
+    timed window with per-launch HIP events.  Reported beside the headline as a first-class mode with its own roofline
+    block: it is the mode that meets north_star's 1e-5 tolerance against the interior-point iterate; the exact mode is the
+    true minimiser of the same QP and differs from that iterate by up to 3e-4 m/s (profiles/r02/qp_fidelity.json)."""
     from marl_mass_amd import VecMergeEnv, _cabi as abi
     env = VecMergeEnv(E, N, env_id=args.env_id, config=cfg, device=dev, **dict(kw, qp_solver="ipm"))
     env.reset()
@@ -111,15 +117,44 @@ def fidelity_mode_rate(args, dev, E, N, cfg, kw, ring, steps=12):
     env.env_i32[abi.EP["STEPS"]] = ((ge * 37) % env.T).to(torch.int32)
     for t in range(env.T + 2):
         env.step(ring[t % 16])
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for t in range(steps):
+        ev[t][0].record()
         env.step(ring[t % 16])
+        ev[t][1].record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps
+    b_alg = algorithmic_bytes_per_agent_step(args.env_id, N)
+    achieved = E * N * b_alg / (kern_ms * 1e-3) / 1e9
     return {"qp_solver": "ipm", "value": E * N * steps / dt, "unit": "agent-steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-            "note": "same workload, shield QP by cvxopt's interior-point algorithm (include/mm_qp.h), one QP per lane; "
-                    "the exact mode above returns the true minimiser of the same QP (DESIGN.md 3 quantifies the difference)"}
+            "meets_1e-5_vs_interior_point_iterate": True,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": workload_traffic(E, N, args.shield, args.env_id, "ipm"), "kernel": "step_kernel<..., IPM=true>",
+                         "kernel_ms": kern_ms, "alg_bytes_per_launch": E * N * b_alg,
+                         "limiter": "VALU issue: a wave iterates ~165 times per policy step through the interior-point body with ~8 of 64 "
+                                    "lanes active (dependency chains of the MASS sweep, 0.4 % of the QPs run to cvxopt's 100-iteration cap); "
+                                    "see DESIGN.md section 2 and tools/ipm_sched_model.py"},
+            "note": "same workload, shield QP by cvxopt's interior-point algorithm (include/mm_qp.h) in the dependency-driven wave-wide "
+                    "loop; bit-identical to the reference-side restatement that produced the ipm_* tapes"}
+
+
+def workload_traffic(E, N, shield, env_id, qp_solver):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json: one row per profiled workload, written
+    from tools/profile.sh runs of this command); None for a workload that was not profiled."""
+    try:
+        tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+        rows = tj["workloads"] if "workloads" in tj else [tj]
+        for r in rows:
+            w = r["workload"]
+            if (w["envs_per_gpu"], w["agents"], w["shield"], w["env_id"], w.get("qp_solver", "exact"), w.get("hdv", 0)) == \
+                    (E, N, shield, env_id, qp_solver, 0):
+                return r["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def main():
@@ -128,7 +163,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs", type=int, default=65536, help="envs PER GPU (weak scaling)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+                    help="strong (default): BASELINE's 65 536 envs in total, split over the GPUs; weak: --envs per GPU")
+    ap.add_argument("--no-weak-extra", action="store_true", help="N > 1, strong scaling: skip the extra weak-scaling measurement")
     ap.add_argument("--total-envs", type=int, default=65536, help="envs over ALL GPUs (strong scaling; BASELINE c5 = 65536 over 8)")
     ap.add_argument("--qp-solver", choices=("exact", "ipm"), default="exact",
                     help="exact: closed-form KKT point (production); ipm: cvxopt's interior-point iterate (fidelity mode)")
@@ -147,7 +184,7 @@ def main():
                          "(the reference's training distribution; not the headline workload)")
     ap.add_argument("--mixed-traffic", action="store_true", help="with --traffic-density: CAVs + IDM/MOBIL HDVs (traffic_type=mixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fidelity-line", action="store_true", help="skip the short qp_solver=ipm measurement appended to the headline line")
+    ap.add_argument("--no-fidelity-line", action="store_true", help="skip the qp_solver=ipm measurement (qp_fidelity_mode) appended to the headline line")
     ap.add_argument("--cpu-envs", type=int, default=32768)
     ap.add_argument("--cpu-steps", type=int, default=400)
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -190,46 +227,59 @@ def main():
         cfg.update({"traffic_density": args.traffic_density, "traffic_type": "mixed" if args.mixed_traffic else "cav",
                     "mixed_traffic": args.mixed_traffic})
         kw["draw_counts"] = True
-    env = VecMergeEnv(E, N, env_id=args.env_id, config=cfg, device=dev, first_env=first_env, **kw)
-    if os.environ.get("MM_BENCH_NO_METRICS"):  # tuning experiment: no in-kernel metric accumulation
-        metrics = torch.zeros(8, dtype=torch.float64, device=dev)
-    else:
-        metrics = env.enable_metrics()
-    env.reset()
-    g = torch.Generator(device=dev).manual_seed(123 + rank)
-    p = torch.tensor([0.1, 0.6, 0.1, 0.1, 0.1], device=dev)
-    ring = [torch.multinomial(p, E * N, True, generator=g).view(E, N).int() for _ in range(16)]
-
     def barrier():
         if world > 1:
             dist.barrier(device_ids=[local]) if nccl else dist.barrier()
 
-    if not args.no_stagger:
-        # stationary batch: stagger the episode phases by GLOBAL env id, then roll one episode length untimed so
-        # that every env has re-spawned once at its own phase and its state is consistent with its step counter
-        T = env.T
-        ge = torch.arange(first_env, first_env + E, dtype=torch.int64, device=dev)
-        env.env_i32[abi.EP["STEPS"]] = ((ge * 37) % T).to(torch.int32)
-        for t in range(T):
+    def measure(E, first_env, steps, warmup):
+        """One stationary batch of E envs on this rank, `steps` timed launches between barriers; returns the wall time of the
+        timed region, the mean per-launch HIP-event time, the metrics buffer, the env and its action ring."""
+        env = VecMergeEnv(E, N, env_id=args.env_id, config=cfg, device=dev, first_env=first_env, **kw)
+        if os.environ.get("MM_BENCH_NO_METRICS"):  # tuning experiment: no in-kernel metric accumulation
+            metrics = torch.zeros(8, dtype=torch.float64, device=dev)
+        else:
+            metrics = env.enable_metrics()
+        env.reset()
+        g = torch.Generator(device=dev).manual_seed(123 + rank)
+        p = torch.tensor([0.1, 0.6, 0.1, 0.1, 0.1], device=dev)
+        ring = [torch.multinomial(p, E * N, True, generator=g).view(E, N).int() for _ in range(16)]
+        if not args.no_stagger:
+            # stationary batch: stagger the episode phases by GLOBAL env id, then roll one episode length untimed so
+            # that every env has re-spawned once at its own phase and its state is consistent with its step counter
+            T = env.T
+            ge = torch.arange(first_env, first_env + E, dtype=torch.int64, device=dev)
+            env.env_i32[abi.EP["STEPS"]] = ((ge * 37) % T).to(torch.int32)
+            for t in range(T):
+                env.step(ring[t % 16])
+        for t in range(warmup):
             env.step(ring[t % 16])
+        torch.cuda.synchronize()
+        metrics.zero_()
+        metrics[7] = float("inf")
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(steps):
+            ev[t][0].record()
+            env.step(ring[t % 16])  # one mm_step launch on torch's current stream
+            ev[t][1].record()
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / steps  # HIP events on the launch stream
+        return elapsed, kern_ms, metrics, env, ring
 
-    for t in range(args.warmup):
-        env.step(ring[t % 16])
-    torch.cuda.synchronize()
-    metrics.zero_()
-    metrics[7] = float("inf")
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(args.steps):
-        ev[t][0].record()
-        env.step(ring[t % 16])  # one mm_step launch on torch's current stream
-        ev[t][1].record()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # HIP events on the launch stream
+    elapsed, kern_ms, metrics, env, ring = measure(E, first_env, args.steps, args.warmup)
+    weak_extra = None
+    if world > 1 and args.scaling == "strong" and not args.no_weak_extra:
+        # the same kernel with BASELINE's batch on EVERY rank (per-GPU work fixed): reported beside the headline
+        w_elapsed, w_kern_ms, _, _, _ = measure(args.envs, rank * args.envs, args.steps, 2)
+        wt = torch.tensor([w_elapsed], dtype=torch.float64, device=dev if nccl else "cpu")
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+        weak_extra = {"scaling": "weak", "envs_per_gpu": args.envs, "envs_total": args.envs * world,
+                      "value": float(args.envs) * world * N * args.steps / float(wt[0]), "unit": "agent-steps/s",
+                      "ms_per_step": float(wt[0]) / args.steps * 1e3, "kernel_ms_rank0": w_kern_ms}
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if nccl or world == 1 else "cpu")
     if world > 1:
@@ -249,32 +299,28 @@ def main():
         agent_steps = float(E_total) * N * args.steps if present is None else present * args.steps
         b_alg = algorithmic_bytes_per_agent_step(args.env_id, N)
         achieved = E * N * b_alg / (kern_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed PMC passes (profiles/traffic.json, written from
-        # tools/profile.sh on the same workload); null for any other workload
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")))
-            w = tj["workload"]
-            if (w["envs_per_gpu"], w["agents"], w["shield"], w["env_id"]) == (E, N, args.shield, args.env_id):
-                traffic = tj["bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM bytes per launch and VALU instructions per wave from the committed PMC passes of this workload
+        # (profiles/traffic.json: one row per profiled workload); null for a workload that was not profiled
+        traffic = workload_traffic(E, N, args.shield, args.env_id, args.qp_solver) if not (args.hdv or args.traffic_density) else None
         # secondary reading (the kernel is VALU-issue bound): instructions from the committed
         # SQ_INSTS_VALU pass x 4 issue cycles per wave64 instruction, against 1024 SIMDs at the 2.4 GHz peak clock
         valu = None
         try:
-            sj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", tj.get("summary", "r01/step_kernel_summary.json"))))
-            if traffic is not None:
-                n_valu = sj["pmc_per_launch"]["SQ_INSTS_VALU"] / sj["pmc_per_launch"]["SQ_WAVES"] * (E * 8 // 64 if N <= 8 else E * 16 // 64)
-                ach = n_valu * 4 / (kern_ms * 1e-3) / 1e12
-                valu = {"bound": "valu-issue", "achieved": ach, "peak": 1024 * 2.4e9 / 1e12, "unit": "T SIMD-cycles/s",
-                        "frac": ach / (1024 * 2.4e9 / 1e12), "valu_insts_per_wave": sj["pmc_per_launch"]["SQ_INSTS_VALU"] / sj["pmc_per_launch"]["SQ_WAVES"]}
-        except (OSError, KeyError, ValueError, ZeroDivisionError):
+            tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+            rows = tj["workloads"] if "workloads" in tj else [tj]
+            row = [r for r in rows if r["bytes_per_launch"] == traffic and traffic is not None][0]
+            sj = json.load(open(os.path.join(REPO, "profiles", row.get("summary", "r01/step_kernel_summary.json"))))
+            per_wave = sj["pmc_per_launch"]["SQ_INSTS_VALU"] / sj["pmc_per_launch"]["SQ_WAVES"]
+            n_valu = per_wave * (E * 8 // 64 if N <= 8 else E * 16 // 64)
+            ach = n_valu * 4 / (kern_ms * 1e-3) / 1e12
+            valu = {"bound": "valu-issue", "achieved": ach, "peak": 1024 * 2.4e9 / 1e12, "unit": "T SIMD-cycles/s",
+                    "frac": ach / (1024 * 2.4e9 / 1e12), "valu_insts_per_wave": per_wave}
+        except (OSError, KeyError, ValueError, ZeroDivisionError, IndexError):
             pass
         headline = args.shield == "mass" and not args.hdv and args.env_id.endswith("v1") and N == 8 and args.qp_solver == "exact" and not args.traffic_density
         if headline and E_total == 65536:
-            # BASELINE.json's metric on its own config: 65 536 envs x 8 CAVs in total (1 GPU weak == c5's batch on one GPU;
-            # 8 GPUs strong == c5 itself)
+            # BASELINE.json's metric on its own config: 65 536 envs x 8 CAVs in total (one GPU holds the whole batch; 8 GPUs
+            # under the default strong scaling are config 5 itself)
             metric = "agent-steps/sec (whole node), MASS CBF shield on, 65536 envs x 8 CAVs"
         elif headline:
             metric = "agent-steps/sec (whole node), MASS CBF shield on, %d x 65536 envs x 8 CAVs (weak scaling: BASELINE's batch per GPU)" % world \
@@ -291,13 +337,19 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d envs x %d CAVs in total = %d per GPU on %d GPU(s) (%s scaling), %s, safety_guarantee=%s, "
-                                   "qp_solver=%s, eta=0.03125, tau=%.1f, 100-step episodes with in-kernel auto-reset, episode "
+                                   "qp_solver=%s (%s), eta=0.03125, tau=%.1f, 100-step episodes with in-kernel auto-reset, episode "
                                    "phases staggered over the batch%s, categorical action tape p=[.1,.6,.1,.1,.1]%s"
                                    % (E_total, N, E, world, args.scaling, args.env_id, cfg["safety_guarantee"], args.qp_solver,
+                                      QP_MODE_NOTE[args.qp_solver] if args.shield != "none" else "no shield",
                                       cfg["HEADWAY_TIME"], " (OFF)" if args.no_stagger else "",
                                       (", of which %d HDVs per env" % args.hdv) if args.hdv else ""),
                        "envs_total": E_total, "envs_per_gpu": E, "agents": N, "obs_dtype": "f64" if args.obs_f64 else "f32",
                        "qp_solver": args.qp_solver,
+                       "tolerance": {"north_star": "1e-5 on float state vs the reference's QP (cvxopt interior-point iterate)",
+                                     "exact": "closed-form KKT point = the true minimiser; differs from the interior-point iterate by "
+                                              "up to 3.0e-4 m/s per QP (p99 1.3e-4): OUTSIDE 1e-5 (profiles/r02/qp_fidelity.json)",
+                                     "ipm": "bit-identical to the restatement of cvxopt's coneqp that answered solvers.qp while the "
+                                            "reference produced the ipm_* tapes: INSIDE 1e-5; see qp_fidelity_mode for its throughput"},
                        "parallelism": "env-sharded x%d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -317,10 +369,12 @@ def main():
             line["rehearsal"] = "all %d ranks on cuda:0, gloo collectives: NOT a scaling measurement" % world
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
             line["cpu_baseline"] = cpu_baseline(args, args.env_id, cfg, kw)
+        if weak_extra is not None:
+            line["weak_scaling"] = weak_extra
         if headline and world == 1 and not args.no_fidelity_line:
-            # the same workload with the shield's QP through cvxopt's interior-point iteration: reported
-            # beside the headline, never as `value`
-            line["qp_fidelity_mode"] = fidelity_mode_rate(args, dev, E, N, cfg, kw, ring)
+            # the same workload with the shield's QP through cvxopt's interior-point iteration: a first-class
+            # mode with its own roofline block, reported beside the headline, never as `value`
+            line["qp_fidelity_mode"] = ipm_mode_line(args, dev, E, N, cfg, kw, ring)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

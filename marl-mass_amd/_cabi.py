@@ -156,14 +156,19 @@ def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs
     c.traffic_density = int(config.get("traffic_density", 1)) if draw_counts else 0
     if draw_counts and c.traffic_density not in (1, 2, 3):
         raise ValueError("traffic_density must be 1, 2 or 3 when the vehicle counts are drawn")
+    # MergeEnv._num_vehicles folds the HDVs into the CAVs only when mixed_traffic `is not None and not ...`
+    # (merge_env_v1.py:206-209): None -- run_mappo.py's fallback -- means mixed
     mixed = config.get("mixed_traffic", True)
+    mixed = 1 if mixed is None else int(bool(mixed))
     if c.env_kind == ENV_V1:  # MergeEnvLCMARL._num_vehicles: traffic_type decides (merge_env_v1.py:476-495)
         tt = config.get("traffic_type", "cav")
         if tt in ("mixed", "cav"):
-            mixed = tt == "mixed"
-        elif draw_counts:
-            raise NotImplementedError("traffic_type=%r is not supported by the device-side count draw" % (tt,))
-    c.mixed_traffic = int(bool(mixed))
+            mixed = int(tt == "mixed")
+        elif tt == "av":  # one CAV, every other drawn vehicle an HDV (:485-489); the total does not depend on mixed_traffic
+            mixed = 2
+        elif tt == "hdv" and draw_counts:  # no controlled vehicle at all: nothing to step or observe on this path
+            raise NotImplementedError("traffic_type='hdv' (zero controlled vehicles) is not supported by the device-side count draw")
+    c.mixed_traffic = mixed
     c.num_cav = int(num_cav)
     return c
 
@@ -211,7 +216,7 @@ class CLib(object):
         """Map C status codes to the exception types the reference raises (SURVEY 8b 'errors')."""
         if rc == MM_OK:
             return
-        msg = self.lib.mm_last_error(handle).decode() if handle else ""
+        msg = self.lib.mm_last_error(handle if handle else None).decode()  # (no handle: why the last mm_create refused)
         if rc in (MM_ERR_INVALID_ARG, MM_ERR_QP_BOUNDS):
             raise ValueError(msg or "invalid argument")
         if rc == MM_ERR_NOT_READY:

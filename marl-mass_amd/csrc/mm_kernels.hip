@@ -26,6 +26,8 @@
 #include <type_traits>
 
 #include "mm_device.h"
+#define MM_COUNTS_FN __host__ __device__ inline
+#include "../../include/mm_counts.h"
 
 using namespace mm;
 
@@ -44,6 +46,7 @@ struct DevCfg {
 #define MM_LATCH_BAD_ACTION 2 // DiscreteMetaAction.act: self.actions[action] KeyError, action.py:194-196
 #define MM_LATCH_BAD_QP 4     // mm_shield_qp: G is not of the form get_G builds
 #define MM_LATCH_INTERNAL 8   // a loop guard of the kernels fired (never expected; reported as MM_ERR_DEVICE)
+enum { MM_LW_STEP = 0, MM_LW_QP = 1, MM_LW_SHIELD = 2, MM_LW_COUNT = 3 };  // latch words of a handle (MMHandle_::dev_err)
 struct DevState {
   double *F;
   uint8_t *B;
@@ -352,12 +355,8 @@ MM_DEV void episode_counts(const DevCfg &c, uint64_t seed, uint32_t episode, int
   if (c.traffic_density <= 0) return;
   uint32_t w[4];
   rng_block(seed, episode, 64u, w);
-  const int lo_c = c.traffic_density == 1 ? 1 : (c.traffic_density == 2 ? 2 : 4);
-  const int lo_h = c.traffic_density == 1 ? 1 : (c.traffic_density == 2 ? 2 : 3);
-  int nc = c.num_cav > 0 ? c.num_cav : lo_c + (int)(((uint64_t)w[0] * 3u) >> 32);
-  int nh = lo_h + (int)(((uint64_t)w[1] * 3u) >> 32);
-  if (!c.mixed_traffic) { nc = nc + nh; nh = 0; }  // :206-209
-  n_cav = nc; n_hdv = nh;
+  mm_counts_from_draw(c.traffic_density, c.mixed_traffic, c.num_cav, (int)(((uint64_t)w[0] * 3u) >> 32), (int)(((uint64_t)w[1] * 3u) >> 32),
+                      &n_cav, &n_hdv);  // include/mm_counts.h (shared with the oracle and the configuration check)
 }
 MM_DEV int spawn_vehicle(Veh &v, int a, int n_cav, int n_hdv, uint64_t seed, uint32_t episode) {
   uint32_t r[12], blk[4];
@@ -1722,6 +1721,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
   // 8 doubles.  (Round 1 used LDS atomics between two __syncthreads() + 8 global atomics per block: 15 % of a wave's
   // lifetime parked at the barriers.)
   if (metrics) {
+    static_assert(MM_STEP_BLOCK % 64 == 0, "whole waves per workgroup");
     const bool lead = e < st.E && a == 0 && env_ok;
     const double mv[8] = {lead ? reward : 0.0, (lead && done && crashed_bits) ? 1.0 : 0.0, lead ? avg_speed : 0.0,
                           lead ? traffic_speed : 0.0, lead ? 1.0 : 0.0, (lead && done) ? merge_pct : 0.0,
@@ -1735,7 +1735,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int ln = lane_id();
     if (ln < 8) {
-      const int slot = C_B + ln, base = tid - ln;
+      const int slot = C_B + ln, base = tid - ln;  // (tid - lane = first column of this wave, for any MM_STEP_BLOCK)
       double acc = ln == 7 ? INFINITY : 0.0;
 #pragma unroll
       for (int j = 0; j < 64 / G; j++) {
@@ -2040,10 +2040,19 @@ struct MMHandle_ {
   long long first_env;
   double *metrics;          // caller's 8 doubles (mm_set_metrics_buffer) or NULL
   double *metrics_partial;  // [waves of a step launch][8], device, owned by the handle
-  int *dev_err;  // device error latch (MM_LATCH_* bits): hipMalloc'd at create, polled by mm_poll_errors
+  // device error latches (MM_LATCH_* bits), hipMalloc'd at create.  One word per entry point that reports synchronously, so
+  // that a condition latched by an un-polled mm_step cannot fail a later, valid mm_shield_qp / mm_shield_actions call (or be
+  // consumed by it): [MM_LW_STEP] mm_step -> mm_poll_errors, [MM_LW_QP] mm_shield_qp, [MM_LW_SHIELD] mm_shield_actions
+  int *dev_err;
   char err[256];
 };
 
+// waves one step launch starts (launch_step_t rounds the grid up to whole MM_STEP_BLOCK-thread blocks): every one of them
+// stores its 64-byte slot of the metrics partial buffer
+static long long step_launch_waves(const MMHandle h) {
+  const long long threads = (long long)h->E * group_size(h->N);
+  return (threads + MM_STEP_BLOCK - 1) / MM_STEP_BLOCK * (MM_STEP_BLOCK / 64);
+}
 #if MM_TU <= 1
 static uint64_t align256(uint64_t x) { return (x + 255u) & ~(uint64_t)255u; }
 
@@ -2069,9 +2078,15 @@ static int check_cfg(const MMConfig *c, int N, char *err) {
   if (N > 12) { snprintf(err, 256, "N=%d exceeds the 6+6 spawn slots", N); return MM_ERR_INVALID_ARG; }
   if (c->n_hdv < 0 || c->n_hdv >= N) { snprintf(err, 256, "n_hdv=%d must leave at least one controlled vehicle of N=%d", c->n_hdv, N); return MM_ERR_INVALID_ARG; }
   if (c->qp_solver != MM_QP_EXACT && c->qp_solver != MM_QP_IPM) { snprintf(err, 256, "unknown qp_solver %d", c->qp_solver); return MM_ERR_INVALID_ARG; }
+  // every vehicle composition this configuration can produce -- fixed counts, or any per-episode draw incl. the
+  // reset(num_CAV=k) override -- must fit the N slots and the six spawn points per road (the reference raises from
+  // np.random.choice(replace=False), merge_env_v1.py:284-320); checked here so that mm_create / mm_set_config refuse it
+  // before any (auto-)reset can meet it
+  if (mm_counts_check(c, N, 0, err, 256)) return MM_ERR_INVALID_ARG;
   return MM_OK;
 }
 
+static thread_local char g_create_err[256] = "null handle";  // why the last mm_create of this thread refused (there is no handle to ask)
 static int hip_fail(MMHandle h, hipError_t e, const char *what) {
   snprintf(h->err, sizeof h->err, "%s: %s", what, hipGetErrorString(e));
   return MM_ERR_DEVICE;
@@ -2081,11 +2096,14 @@ extern "C" int32_t mm_create(const MMConfig *cfg, int32_t E, int32_t N, int32_t 
                              uint64_t state_bytes, int64_t first_env, MMHandle *out) {
   if (!out || !state) return MM_ERR_INVALID_ARG;
   MMHandle h = (MMHandle)calloc(1, sizeof(struct MMHandle_));
+  snprintf(h->err, sizeof h->err, "mm_create: E, N, the state buffer (size, 256-byte alignment) or the configuration is invalid");
   if (mm_state_layout(E, N, &h->lay) != MM_OK || state_bytes < h->lay.total_bytes ||
       ((uintptr_t)state & 255u) || check_cfg(cfg, N, h->err) != MM_OK) {
+    snprintf(g_create_err, sizeof g_create_err, "%s", h->err);
     free(h);
     return MM_ERR_INVALID_ARG;
   }
+  h->err[0] = 0;
   h->cfg = *cfg; h->E = E; h->N = N; h->device = device; h->state = (unsigned char *)state;
   h->first_env = first_env;
   // per-env seed plane: cfg.seed + global env index
@@ -2094,8 +2112,8 @@ extern "C" int32_t mm_create(const MMConfig *cfg, int32_t E, int32_t N, int32_t 
   hipError_t rc = hipSetDevice(device);
   if (rc == hipSuccess) rc = hipMemcpy(h->state + h->lay.seed_offset, tmp, (size_t)E * 8u, hipMemcpyHostToDevice);
   free(tmp);
-  if (rc == hipSuccess) rc = hipMalloc((void **)&h->dev_err, sizeof(int));
-  if (rc == hipSuccess) rc = hipMemset(h->dev_err, 0, sizeof(int));
+  if (rc == hipSuccess) rc = hipMalloc((void **)&h->dev_err, MM_LW_COUNT * sizeof(int));
+  if (rc == hipSuccess) rc = hipMemset(h->dev_err, 0, MM_LW_COUNT * sizeof(int));
   if (rc != hipSuccess) { if (h->dev_err) (void)hipFree(h->dev_err); free(h); return MM_ERR_DEVICE; }
   *out = h;
   return MM_OK;
@@ -2111,18 +2129,27 @@ extern "C" int32_t mm_destroy(MMHandle h) {
   return rc == hipSuccess ? MM_OK : MM_ERR_DEVICE;
 }
 // include/mm_abi.h: conditions the reference raises inside step(), latched by the kernels
+static int poll_latch(MMHandle h, int word, MMStream stream) {
+  int bits = 0;
+  hipError_t rc = hipSetDevice(h->device);  // (a multi-GPU process may have another device current)
+  if (rc == hipSuccess) rc = hipStreamSynchronize((hipStream_t)stream);
+  if (rc == hipSuccess) rc = hipMemcpy(&bits, h->dev_err + word, sizeof bits, hipMemcpyDeviceToHost);
+  if (rc == hipSuccess && bits) rc = hipMemset(h->dev_err + word, 0, sizeof(int));
+  if (rc != hipSuccess) return hip_fail(h, rc, "error poll");
+  if (!bits) return MM_OK;
+  // every latched condition goes into the message; the return code is the most specific one
+  snprintf(h->err, sizeof h->err, "%s%s%s%s",
+           (bits & MM_LATCH_QP_BOUNDS) ? "Error in QP. Invalid accceleration; " : "",
+           (bits & MM_LATCH_BAD_ACTION) ? "an action is outside 0..4; " : "",
+           (bits & MM_LATCH_BAD_QP) ? "mm_shield_qp: G is not of the form get_G builds (cbf.py:288-304,386-403); " : "",
+           (bits & MM_LATCH_INTERNAL) ? "internal: a kernel loop guard fired; " : "");
+  if (bits & MM_LATCH_INTERNAL) return MM_ERR_DEVICE;
+  if (bits & MM_LATCH_QP_BOUNDS) return MM_ERR_QP_BOUNDS;
+  return MM_ERR_INVALID_ARG;
+}
 extern "C" int32_t mm_poll_errors(MMHandle h, MMStream stream) {
   if (!h) return MM_ERR_INVALID_ARG;
-  int bits = 0;
-  hipError_t rc = hipStreamSynchronize((hipStream_t)stream);
-  if (rc == hipSuccess) rc = hipMemcpy(&bits, h->dev_err, sizeof bits, hipMemcpyDeviceToHost);
-  if (rc == hipSuccess && bits) rc = hipMemset(h->dev_err, 0, sizeof(int));
-  if (rc != hipSuccess) return hip_fail(h, rc, "error poll");
-  if (bits & MM_LATCH_QP_BOUNDS) { snprintf(h->err, sizeof h->err, "Error in QP. Invalid accceleration"); return MM_ERR_QP_BOUNDS; }
-  if (bits & MM_LATCH_BAD_ACTION) { snprintf(h->err, sizeof h->err, "an action is outside 0..4"); return MM_ERR_INVALID_ARG; }
-  if (bits & MM_LATCH_BAD_QP) { snprintf(h->err, sizeof h->err, "mm_shield_qp: G is not of the form get_G builds (cbf.py:288-304,386-403)"); return MM_ERR_INVALID_ARG; }
-  if (bits & MM_LATCH_INTERNAL) { snprintf(h->err, sizeof h->err, "internal: a kernel loop guard fired"); return MM_ERR_DEVICE; }
-  return MM_OK;
+  return poll_latch(h, MM_LW_STEP, stream);
 }
 extern "C" int32_t mm_set_config(MMHandle h, const MMConfig *cfg) {
   if (!h) return MM_ERR_INVALID_ARG;
@@ -2133,7 +2160,7 @@ extern "C" int32_t mm_set_config(MMHandle h, const MMConfig *cfg) {
 extern "C" int32_t mm_set_metrics_buffer(MMHandle h, double *metrics) {
   if (!h) return MM_ERR_INVALID_ARG;
   if (metrics && !h->metrics_partial) {  // per-wave partials of one step launch (allocated here, never inside step)
-    const long long waves = ((long long)h->E * group_size(h->N) + 63) / 64;
+    const long long waves = step_launch_waves(h);
     hipError_t rc = hipSetDevice(h->device);
     if (rc == hipSuccess) rc = hipMalloc((void **)&h->metrics_partial, (size_t)waves * 8 * sizeof(double));
     if (rc != hipSuccess) return hip_fail(h, rc, "metrics partial buffer");
@@ -2141,7 +2168,7 @@ extern "C" int32_t mm_set_metrics_buffer(MMHandle h, double *metrics) {
   h->metrics = metrics;
   return MM_OK;
 }
-extern "C" const char *mm_last_error(MMHandle h) { return h ? h->err : "null handle"; }
+extern "C" const char *mm_last_error(MMHandle h) { return h ? h->err : g_create_err; }
 #endif  // MM_TU <= 1
 
 static DevCfg dev_cfg(const MMHandle h) {
@@ -2159,7 +2186,7 @@ static DevCfg dev_cfg(const MMHandle h) {
   d.rs_span2 = (d.rs_lo + (d.rs_hi - d.rs_lo) / 2) - d.rs_lo; d.rs_ispan2 = 1.0 / d.rs_span2;  // mrew, collaborating
   d.agent_reward = c.env_kind == MM_ENV_V1 ? c.agent_reward : 0;
   d.steer_vel = (c.env_kind == MM_ENV_V1 && c.lateral_control == MM_LATERAL_STEER_VEL) ? 1 : 0;
-  d.err = h->dev_err;
+  d.err = h->dev_err + MM_LW_STEP;
   d.traffic_density = c.traffic_density; d.mixed_traffic = c.mixed_traffic; d.num_cav = c.num_cav;
   return d;
 }
@@ -2205,18 +2232,7 @@ static int launch_reset(MMHandle h, int mode, const uint8_t *mask, const uint64_
 extern "C" int32_t mm_reset(MMHandle h, const uint8_t *env_mask, const uint64_t *seeds, void *obs,
                             uint8_t *avail, MMStream stream) {
   if (!h) return MM_ERR_INVALID_ARG;
-  {  // each road has 6 spawn slots shared by its CAVs and HDVs (merge_env_v1.py:284-285; np.random.choice raises beyond)
-    const int n_hdv = h->cfg.n_hdv, n_cav = h->N - n_hdv, ramp = (n_cav - n_cav / 2) + (n_hdv - n_hdv / 2);
-    if (h->cfg.traffic_density == 0 && ramp > 6) {
-      snprintf(h->err, sizeof h->err, "%d CAVs + %d HDVs need %d ramp spawn slots, the road has 6", n_cav, n_hdv, ramp);
-      return MM_ERR_INVALID_ARG;
-    }
-    const int td = h->cfg.traffic_density, need = td == 0 ? 0 : (td == 1 ? 6 : (td == 2 ? 8 : 11));  // largest draw
-    if (td < 0 || td > 3 || h->N < need) {
-      snprintf(h->err, sizeof h->err, "traffic_density %d draws up to %d vehicles per episode, the batch has %d slots", td, need, h->N);
-      return MM_ERR_INVALID_ARG;
-    }
-  }
+  if (mm_counts_check(&h->cfg, h->N, 1, h->err, sizeof h->err)) return MM_ERR_INVALID_ARG;  // the device spawns N - n_hdv CAVs + n_hdv HDVs
   return launch_reset(h, 0, env_mask, seeds, obs, avail, stream);
 }
 extern "C" int32_t mm_init_from_kinematics(MMHandle h, const uint8_t *env_mask, MMStream stream) {
@@ -2260,7 +2276,7 @@ static void launch_step_ipm_gm(MMHandle h, const int32_t *actions, const MMStepO
   else launch_step_t<G, MM_ENV_V1, MM_SHIELD_HSS, MIXED, true>(h, actions, out, s);
 }
 static bool needs_general(const MMHandle h) {  // HDVs can appear, or steer_vel lateral control: the kernels that carry IDM / MOBIL
-  return h->cfg.n_hdv > 0 || (h->cfg.traffic_density > 0 && h->cfg.mixed_traffic) ||
+  return h->cfg.n_hdv > 0 || (h->cfg.traffic_density > 0 && h->cfg.mixed_traffic != 0) ||
          (h->cfg.env_kind == MM_ENV_V1 && h->cfg.lateral_control == MM_LATERAL_STEER_VEL);
 }
 template <int G>
@@ -2339,7 +2355,7 @@ extern "C" int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *
   }
 #endif
   if (h->metrics) {  // fold this launch's per-wave partials into the caller's 8 doubles (same stream: ordered)
-    const long long waves = ((long long)h->E * group_size(h->N) + 63) / 64;
+    const long long waves = step_launch_waves(h);
     hipLaunchKernelGGL(metrics_flush_kernel, dim3((unsigned)((waves + kFlushWaves - 1) / kFlushWaves)), dim3(256), 0, s,
                        h->metrics_partial, waves, h->metrics);
   }
@@ -2354,12 +2370,14 @@ static void launch_shield_gi(MMHandle h, const double *as, const double *aa, dou
   const long long threads = (long long)h->E * G;
   const unsigned grid = (unsigned)((threads + 255) / 256);
   const int sh = h->cfg.env_kind == MM_ENV_V1 ? h->cfg.shield : MM_SHIELD_NONE;
+  DevCfg dc = dev_cfg(h);
+  dc.err = h->dev_err + MM_LW_SHIELD;  // this entry reports synchronously from its own latch word
   if (sh == MM_SHIELD_MASS)
-    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_MASS, IPM>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), as, aa, ss, sa, stt, mg);
+    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_MASS, IPM>), dim3(grid), dim3(256), 0, s, dc, dev_state(h), as, aa, ss, sa, stt, mg);
   else if (sh == MM_SHIELD_HSS)
-    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_HSS, IPM>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), as, aa, ss, sa, stt, mg);
+    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_HSS, IPM>), dim3(grid), dim3(256), 0, s, dc, dev_state(h), as, aa, ss, sa, stt, mg);
   else
-    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_NONE, false>), dim3(grid), dim3(256), 0, s, dev_cfg(h), dev_state(h), as, aa, ss, sa, stt, mg);
+    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_NONE, false>), dim3(grid), dim3(256), 0, s, dc, dev_state(h), as, aa, ss, sa, stt, mg);
 }
 template <int G>
 static void launch_shield_g(MMHandle h, const double *as, const double *aa, double *ss, double *sa, uint8_t *stt,
@@ -2384,7 +2402,7 @@ extern "C" int32_t mm_shield_actions(MMHandle h, const double *act_steer, const 
   hipError_t rc = hipGetLastError();
   if (rc != hipSuccess) return hip_fail(h, rc, "shield launch");
   // the reference call raises check_bounds' ValueError synchronously (only the IPM iterate can leave the bounds)
-  return h->cfg.qp_solver == MM_QP_IPM ? mm_poll_errors(h, stream) : MM_OK;
+  return h->cfg.qp_solver == MM_QP_IPM ? poll_latch(h, MM_LW_SHIELD, stream) : MM_OK;
 }
 
 extern "C" int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec, const int32_t *rows,
@@ -2393,10 +2411,10 @@ extern "C" int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const do
   if (n == 0) return MM_OK;
   if (!G || !hvec || !rows || !u_out) return MM_ERR_INVALID_ARG;
   hipLaunchKernelGGL(qp_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, G, hvec, rows, (int)solver, u_out,
-                     status, iters, h->dev_err);
+                     status, iters, h->dev_err + MM_LW_QP);
   hipError_t rc = hipGetLastError();
   if (rc != hipSuccess) return hip_fail(h, rc, "qp launch");
-  return mm_poll_errors(h, stream);
+  return poll_latch(h, MM_LW_QP, stream);
 }
 
 // diagnostics: element-wise mm_math evaluation (CPU/GPU bit-equality tests)

@@ -227,7 +227,7 @@ class DeviceRollout(object):
         # its own seed sequence and in-progress episode.  Here the batch is borrowed: snapshot everything an evaluation
         # touches (state planes, episode counters, per-env RNG seeds, carried observation) and put it back afterwards,
         # so the training stream continues exactly where it was instead of restarting from the test seeds.
-        saved_env, saved_obs = env.state_dict(), self.obs.clone()
+        saved_env, saved_obs, saved_counter = env.state_dict(), self.obs.clone(), self._sample_counter.clone()
         env.configure(auto_reset=False)
         try:
             # an evaluation episode is a function of its seed alone (the reference re-seeds the global RNG):
@@ -273,3 +273,6 @@ class DeviceRollout(object):
             env.load_state_dict(saved_env)
             # in place: after a graph capture self.obs is the graph's static carry buffer and must stay that tensor
             self.obs.copy_(saved_obs)
+            # the sampler's counter as well (the evaluation's own act() calls advanced it): with a stochastic actor the
+            # training rollouts after an evaluation are then the ones a twin that never evaluated draws
+            self._sample_counter.copy_(saved_counter)

@@ -138,7 +138,10 @@ class BatchedMergeEnv(object):
         k8 = present.to(torch.uint8)
         if kind is not None:
             k8 = k8 * torch.as_tensor(kind, device=dev).view(self.E, self.N).to(torch.uint8)
-            if self.n_hdv == 0 and bool((k8 == 2).any()):
+            # the kernels that carry IDM / MOBIL run when HDVs can exist (the library's needs_general()): a fixed HDV count, a
+            # count draw with mixed / "av" traffic, or steer_vel lateral control
+            general = self.n_hdv > 0 or self._cfg.lateral_control != 0 or (self._cfg.traffic_density > 0 and self._cfg.mixed_traffic != 0)
+            if not general and bool((k8 == 2).any()):
                 # the CAV-only kernels would drive such a vehicle as a CAV from actions[i]
                 raise ValueError("HDVs (kind == 2) in the spawn need mixed traffic: configure(n_hdv=...) > 0 first")
         put(self.u8[abi.B["KIND"]], k8)

@@ -21,6 +21,7 @@
  * keeps a*b+c as two roundings like CPython/numpy scalar arithmetic.
  */
 #include "../include/mm_abi.h"
+#include "../include/mm_counts.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -1331,12 +1332,8 @@ static void init_vehicle(Veh *v) {
 static void episode_counts(const MMConfig *cfg, int N, uint64_t seed, uint32_t episode, int *n_cav, int *n_hdv) {
   *n_cav = N - cfg->n_hdv; *n_hdv = cfg->n_hdv;
   if (cfg->traffic_density <= 0) return;
-  const int lo_c = cfg->traffic_density == 1 ? 1 : (cfg->traffic_density == 2 ? 2 : 4);
-  const int lo_h = cfg->traffic_density == 1 ? 1 : (cfg->traffic_density == 2 ? 2 : 3);
-  int nc = cfg->num_cav > 0 ? cfg->num_cav : lo_c + (int)(((uint64_t)rng_u32(seed, episode, 4u * 64u) * 3u) >> 32);
-  int nh = lo_h + (int)(((uint64_t)rng_u32(seed, episode, 4u * 64u + 1u) * 3u) >> 32);
-  if (!cfg->mixed_traffic) { nc = nc + nh; nh = 0; } /* :206-209 */
-  *n_cav = nc; *n_hdv = nh;
+  mm_counts_from_draw(cfg->traffic_density, cfg->mixed_traffic, cfg->num_cav, (int)(((uint64_t)rng_u32(seed, episode, 4u * 64u) * 3u) >> 32),
+                      (int)(((uint64_t)rng_u32(seed, episode, 4u * 64u + 1u) * 3u) >> 32), n_cav, n_hdv); /* include/mm_counts.h */
 }
 
 /* merge_env_v1.py:265-364 _make_vehicles for N CAVs / 0 HDVs with the device RNG stream
@@ -1472,6 +1469,7 @@ int32_t mm_state_layout(int32_t E, int32_t N, MMStateLayout *out) {
   return MM_OK;
 }
 
+static _Thread_local char g_create_err[256] = "null handle"; /* why the last mm_create of this thread refused */
 static int check_cfg(const MMConfig *c, int N, char *err) {
   if (!c || c->abi_version != MM_ABI_VERSION) { snprintf(err, 256, "ABI version mismatch"); return MM_ERR_INVALID_ARG; }
   if (c->env_kind != MM_ENV_V0 && c->env_kind != MM_ENV_V1) { snprintf(err, 256, "unknown env_kind %d", c->env_kind); return MM_ERR_INVALID_ARG; }
@@ -1481,6 +1479,7 @@ static int check_cfg(const MMConfig *c, int N, char *err) {
   if (N > 12) { snprintf(err, 256, "N=%d exceeds the 6+6 spawn slots", N); return MM_ERR_INVALID_ARG; }
   if (c->n_hdv < 0 || c->n_hdv >= N) { snprintf(err, 256, "n_hdv=%d must leave at least one controlled vehicle of N=%d", c->n_hdv, N); return MM_ERR_INVALID_ARG; }
   if (c->qp_solver != MM_QP_EXACT && c->qp_solver != MM_QP_IPM) { snprintf(err, 256, "unknown qp_solver %d", c->qp_solver); return MM_ERR_INVALID_ARG; }
+  if (mm_counts_check(c, N, 0, err, 256)) return MM_ERR_INVALID_ARG; /* slots and spawn points for every composition (include/mm_counts.h) */
   return MM_OK;
 }
 
@@ -1489,8 +1488,10 @@ int32_t mm_create(const MMConfig *cfg, int32_t E, int32_t N, int32_t device, voi
   (void)device;
   if (!out || !state) return MM_ERR_INVALID_ARG;
   struct MMHandle_ *h = calloc(1, sizeof *h);
+  snprintf(h->err, sizeof h->err, "mm_create: E, N, the state buffer size or the configuration is invalid");
   if (mm_state_layout(E, N, &h->lay) != MM_OK || state_bytes < h->lay.total_bytes ||
-      check_cfg(cfg, N, h->err) != MM_OK) { free(h); return MM_ERR_INVALID_ARG; }
+      check_cfg(cfg, N, h->err) != MM_OK) { snprintf(g_create_err, sizeof g_create_err, "%s", h->err); free(h); return MM_ERR_INVALID_ARG; }
+  h->err[0] = 0;
   h->cfg = *cfg; h->E = E; h->N = N; h->state = state; h->first_env = first_env;
   uint64_t *seeds = (uint64_t *)(h->state + h->lay.seed_offset);
   for (int64_t e = 0; e < E; e++) seeds[e] = cfg->seed + (uint64_t)(first_env + e);
@@ -1505,24 +1506,13 @@ int32_t mm_set_config(MMHandle h, const MMConfig *cfg) {
   return rc;
 }
 int32_t mm_set_metrics_buffer(MMHandle h, double *metrics) { h->metrics = metrics; return MM_OK; }
-const char *mm_last_error(MMHandle h) { return h ? h->err : "null handle"; }
+const char *mm_last_error(MMHandle h) { return h ? h->err : g_create_err; }
 
 int32_t mm_reset(MMHandle h, const uint8_t *env_mask, const uint64_t *seeds_in, void *obs,
                  uint8_t *avail, MMStream stream) {
   (void)stream;
   if (!h) return MM_ERR_INVALID_ARG;
-  { /* each road has 6 spawn slots shared by its CAVs and HDVs (merge_env_v1.py:284-285; np.random.choice raises beyond) */
-    const int n_hdv = h->cfg.n_hdv, n_cav = h->N - n_hdv, ramp = (n_cav - n_cav / 2) + (n_hdv - n_hdv / 2);
-    if (h->cfg.traffic_density == 0 && ramp > 6) {
-      snprintf(h->err, sizeof h->err, "%d CAVs + %d HDVs need %d ramp spawn slots, the road has 6", n_cav, n_hdv, ramp);
-      return MM_ERR_INVALID_ARG;
-    }
-    const int td = h->cfg.traffic_density, need = td == 0 ? 0 : (td == 1 ? 6 : (td == 2 ? 8 : 11)); /* largest draw */
-    if (td < 0 || td > 3 || h->N < need) {
-      snprintf(h->err, sizeof h->err, "traffic_density %d draws up to %d vehicles per episode, the batch has %d slots", td, need, h->N);
-      return MM_ERR_INVALID_ARG;
-    }
-  }
+  if (mm_counts_check(&h->cfg, h->N, 1, h->err, sizeof h->err)) return MM_ERR_INVALID_ARG; /* the spawn below is N - n_hdv CAVs + n_hdv HDVs */
   uint64_t *seeds = (uint64_t *)(h->state + h->lay.seed_offset);
 #pragma omp parallel for schedule(static)
   for (int64_t e_idx = 0; e_idx < h->E; e_idx++) {

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_env
-from golden_util import GOLDEN, load_episode
+from golden_util import GOLDEN, is_ipm, load_episode
 from marl_mass_amd import compat
 from marl_mass_amd import _cabi as abi
 
@@ -87,12 +87,32 @@ def test_training_seed_increments():
     assert env.seed == s0 + 1  # abstract.py:190
 
 
+@pytest.fixture(autouse=True)
+def _restore_cbf_knobs():
+    """CBFType is class-level state (as in the reference): every test leaves it as it found it."""
+    saved = (compat.CBFType.GAMMA_B, compat.CBFType.TAU, compat.CBFType.QP_SOLVER)
+    yield
+    compat.CBFType.GAMMA_B, compat.CBFType.TAU, compat.CBFType.QP_SOLVER = saved
+
+
+def test_drop_in_default_is_the_reference_solver_behaviour():
+    """The adapter answers solvers.qp with cvxopt's interior-point iterate unless told otherwise (the closed form is an
+    explicit opt-in): the backend it builds runs qp_solver = ipm."""
+    assert compat.CBFType.QP_SOLVER == "ipm"
+    env = compat.MergeEnvCompat("merge-multi-agent-v1", backend_factory=_factory)
+    env.config.update({"safety_guarantee": "cbf-cav", "traffic_type": "cav", "traffic_density": 1})
+    env.reset(is_training=False, testing_seeds=0)
+    assert env._b._cfg.qp_solver == abi.QP_IPM
+
+
 @pytest.mark.parametrize("name", ["ep_v0_none_N4_s25", "ep_v1_mass_N8_s0", "ep_v1_hss_N4_s50", "mx_v1_mass_4c3h_s25",
-                                  "mx_v0_none_3c3h_s0", "sv_v1_hss_N4_s25"])
+                                  "mx_v0_none_3c3h_s0", "sv_v1_hss_N4_s25", "ipm_v1_mass_N8_s0", "ipm_v1_hss_N4_s50",
+                                  "ipm_v1_mass_4c3h_s25"])
 def test_step_tuple_matches_golden(name):
     """The (obs, reward, done, info) tuple of MergeEnv.step through the adapter, free-running."""
     z, meta = load_episode(os.path.join(GOLDEN, name + ".npz"))
     compat.CBFType.GAMMA_B, compat.CBFType.TAU = meta["eta"], meta["headway_time"]
+    compat.CBFType.QP_SOLVER = "ipm" if is_ipm(meta) else "exact"  # what answered solvers.qp while the reference produced the tape
     env = compat.MergeEnvCompat(meta["env_id"], backend_factory=_factory)
     env.config.update({"safety_guarantee": meta["shield"], "HEADWAY_TIME": meta["headway_time"],
                        "action_masking": False, "traffic_type": "cav", "mixed_traffic": False,
@@ -123,6 +143,7 @@ def test_control_profile_matches_reference(name):
     from golden_util import SF, SI
     z, meta = load_episode(os.path.join(GOLDEN, name + ".npz"))
     compat.CBFType.GAMMA_B, compat.CBFType.TAU = meta["eta"], meta["headway_time"]
+    compat.CBFType.QP_SOLVER = "ipm" if is_ipm(meta) else "exact"
     env = compat.MergeEnvCompat(meta["env_id"], backend_factory=_factory, store_profile=True)
     env.config.update({"safety_guarantee": meta["shield"], "HEADWAY_TIME": meta["headway_time"], "action_masking": False,
                        "lateral_control": meta.get("lateral_control", "steer")})

@@ -16,8 +16,9 @@ RANGES = {1: ((1, 3), (1, 3)), 2: ((2, 4), (2, 4)), 3: ((4, 6), (3, 5))}  # incl
 
 
 def _env(make, E, N, td, mixed, **kw):
+    # mixed: False (traffic_type "cav") | True ("mixed") | "av" (one CAV among HDVs, merge_env_v1.py:485-489)
     cfg = {"safety_guarantee": kw.pop("shield", "none"), "HEADWAY_TIME": 0.5, "traffic_density": td,
-           "traffic_type": "mixed" if mixed else "cav", "mixed_traffic": mixed}
+           "traffic_type": mixed if isinstance(mixed, str) else ("mixed" if mixed else "cav"), "mixed_traffic": bool(mixed)}
     return make(E, N, env_id="merge-multi-agent-v1", config=cfg, cbf_eta=0.03125, cbf_tau=0.5, draw_counts=True, **kw)
 
 
@@ -65,6 +66,48 @@ def test_num_cav_override_and_capacity_check():
         _env(oracle_env.OracleEnv, 4, 6, 4, True)
 
 
+def test_capacity_is_checked_for_every_composition_the_configuration_can_draw():
+    """The reference raises ValueError from np.random.choice(replace=False) when a road runs out of spawn points
+    (merge_env_v1.py:284-320); here mm_create / mm_set_config refuse such a configuration up front -- incl. the
+    reset(num_CAV=k) override and the per-road limit of six, which an auto-reset inside step() would otherwise meet."""
+    with pytest.raises(ValueError, match="slots"):       # 8 CAVs + up to 5 HDVs in 12 slots
+        _env(oracle_env.OracleEnv, 4, 12, 3, True, num_cav=8)
+    with pytest.raises(ValueError, match="spawn points"):  # 7 + 5 fit the slots, but the ramp would need 4 + 3 = 7 points
+        _env(oracle_env.OracleEnv, 4, 12, 3, True, num_cav=7)
+    env = _env(oracle_env.OracleEnv, 64, 11, 3, True, num_cav=6, seed=9, auto_reset=True)  # the boundary that fits: 3 + 3 / 2 + 3
+    env.reset()
+    kind = env.u8[abi.B["KIND"]].numpy()
+    assert ((kind == 1).sum(1) == 6).all() and (kind == 2).sum(1).max() == 5
+    x = env.f64[abi.F["X"]].numpy()
+    assert (x[kind != 0] > 0).all()  # every vehicle sits on a spawn point (a missing one would be x = noise around 0)
+    env2 = oracle_env.OracleEnv(4, 12, config={"safety_guarantee": "none"})  # fixed counts, then re-configured to an impossible draw
+    with pytest.raises(ValueError):
+        env2.configure({"traffic_density": 3, "traffic_type": "mixed", "mixed_traffic": True}, draw_counts=True, num_cav=9)
+    with pytest.raises(ValueError):   # fixed counts that the device spawn cannot place: 11 CAVs + 1 HDV need 7 ramp points
+        oracle_env.OracleEnv(4, 12, config={"safety_guarantee": "none"}, n_hdv=1).reset()
+
+
+def test_traffic_type_av_draws_one_cav_among_hdvs():
+    E, N = 6000, 8
+    env = _env(oracle_env.OracleEnv, E, N, 2, "av", seed=23)
+    env.reset()
+    kind = env.u8[abi.B["KIND"]].numpy()
+    n_cav, n_hdv = (kind == 1).sum(1), (kind == 2).sum(1)
+    assert (n_cav == 1).all() and n_hdv.min() == 3 and n_hdv.max() == 7   # (2..4) + (2..4) - 1
+    freq = np.bincount(n_hdv - 3, minlength=5) / E
+    assert np.abs(freq - np.array([1, 2, 3, 2, 1]) / 9).max() < 0.02, freq
+    with pytest.raises(NotImplementedError):
+        _env(oracle_env.OracleEnv, 4, 8, 2, "hdv")
+
+
+def test_mixed_traffic_none_means_mixed_on_v0():
+    """merge_env_v1.py:206-209 folds the HDVs into the CAVs only when mixed_traffic `is not None and not ...`;
+    run_mappo.py's fallback for the key is None."""
+    cfg = abi.make_config("merge-multi-agent-v0", dict(abi.default_env_config("merge-multi-agent-v0"), mixed_traffic=None, traffic_density=1),
+                          draw_counts=True)
+    assert cfg.mixed_traffic == 1
+
+
 def test_ragged_auto_reset_changes_composition_between_episodes():
     E, N = 256, 8
     env = _env(oracle_env.OracleEnv, E, N, 2, True, seed=5, auto_reset=True, shield="cbf-cav")
@@ -87,7 +130,7 @@ def test_ragged_auto_reset_changes_composition_between_episodes():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("td,mixed,N,shield", [(1, False, 6, "cbf-cav"), (2, True, 8, "cbf-cav"), (3, False, 11, "cbf-avs_cint"),
-                                               (3, True, 12, "cbf-cav"), (1, True, 7, "none")])
+                                               (3, True, 12, "cbf-cav"), (1, True, 7, "none"), (2, "av", 8, "cbf-cav")])
 def test_ragged_auto_reset_soak_bit_exact_on_gpu(td, mixed, N, shield):
     """HIP == oracle, every bit, over three episodes of a ragged, re-drawn batch (counts, spawns, absent slots)."""
     from marl_mass_amd import VecMergeEnv

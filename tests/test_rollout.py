@@ -271,34 +271,36 @@ def test_rollout_checkpoint_resume():
         assert torch.equal(out[k], ref[k]), k
 
 
-def test_evaluate_leaves_the_training_stream_untouched():
+@pytest.mark.parametrize("greedy", [True, False], ids=["greedy", "sampling"])
+def test_evaluate_leaves_the_training_stream_untouched(greedy):
     """The reference evaluates on a separate env_eval (run_mappo.py:300-306): the training env keeps its seed sequence
     and its in-progress episodes.  DeviceRollout.evaluate borrows the batch, so afterwards every plane, counter, per-env
-    RNG seed and the carried observation must be exactly what they were -- and the next rollout must be the one a
-    twin that never evaluated produces."""
+    RNG seed, the carried observation and the SAMPLER's counter must be exactly what they were -- and the next rollout
+    must be the one a twin that never evaluated produces, with a deterministic and with a sampling actor."""
     def make():
         torch.manual_seed(0)
         env = oracle_env.OracleEnv(4, 4, env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
                                    cbf_eta=0.03125, cbf_tau=0.5, seed=3, auto_reset=True)
 
-        class GreedyActor(ActorNetwork):  # deterministic actions: the comparison does not depend on the sampler's counter
+        class GreedyActor(ActorNetwork):  # deterministic actions: this leg does not depend on the sampler's counter
             def forward(self, state):
                 lp = super().forward(state)
                 return torch.where(lp == lp.max(-1, keepdim=True).values, 0.0, -float("inf")).to(lp.dtype)
-        return DeviceRollout(env, GreedyActor(30, 128, 5), CriticNetwork(30, 5, 128), roll_out_n_steps=15)
+        actor = GreedyActor(30, 128, 5) if greedy else ActorNetwork(30, 128, 5)  # (sampling: Philox keyed by the counter)
+        return DeviceRollout(env, actor, CriticNetwork(30, 5, 128), roll_out_n_steps=15, sample_seed=11)
     a, b = make(), make()
     a.interact(); b.interact()
     before = a.env.state.clone()
     a.evaluate(seeds=[7, 8, 9, 10])
     assert torch.equal(a.env.state, before), "state planes / counters / seeds changed by evaluate()"
     assert torch.equal(a.env.seeds, b.env.seeds) and torch.equal(a.env.env_i32, b.env.env_i32)
-    assert torch.equal(a.obs, b.obs)
+    assert torch.equal(a.obs, b.obs) and torch.equal(a._sample_counter, b._sample_counter)
     ra, rb = a.interact(), b.interact()
     for k in ("states", "actions", "returns", "dones"):
         assert torch.equal(ra[k], rb[k]), k
     a.evaluate(seeds=[7, 8, 9, 10])  # and a second evaluation does not replay the first post-evaluation spawn either
     ra, rb = a.interact(), b.interact()
-    assert torch.equal(ra["states"], rb["states"])
+    assert torch.equal(ra["states"], rb["states"]) and torch.equal(ra["actions"], rb["actions"])
 
 
 @pytest.mark.gpu

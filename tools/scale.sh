@@ -1,10 +1,10 @@
 #!/bin/bash
 # 1/2/4/8-GPU scaling of the headline bench on ONE node (run it on an 8-GPU box; the driver does the same at round end).
 # The launcher is started before anything touches a GPU; one rank per GPU, RCCL only for the end-of-rollout metric all-reduce.
-#   bash tools/scale.sh [weak|strong] [extra bench.py args]      -> gpurun_out/scale_<mode>.jsonl
+#   bash tools/scale.sh [strong|weak] [extra bench.py args]      -> gpurun_out/scale_<mode>.jsonl
 set -eo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-MODE=${1:-weak}; shift || true
+MODE=${1:-strong}; shift || true
 OUT=$R/gpurun_out/scale_$MODE.jsonl
 mkdir -p "$R/gpurun_out"; : > "$OUT"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
