@@ -183,6 +183,8 @@ def main():
                          "then the slot capacity (>= 6 / 8 / 11) of a ragged batch and agent-steps count the vehicles actually present "
                          "(the reference's training distribution; not the headline workload)")
     ap.add_argument("--mixed-traffic", action="store_true", help="with --traffic-density: CAVs + IDM/MOBIL HDVs (traffic_type=mixed)")
+    ap.add_argument("--all-outputs", action="store_true", help="also write agents_info / action_mask / crashed every step (30 B per agent "
+                                                                "that B_alg does not count and the rollout loop does not read)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fidelity-line", action="store_true", help="skip the qp_solver=ipm measurement (qp_fidelity_mode) appended to the headline line")
     ap.add_argument("--cpu-envs", type=int, default=32768)
@@ -234,7 +236,10 @@ def main():
     def measure(E, first_env, steps, warmup):
         """One stationary batch of E envs on this rank, `steps` timed launches between barriers; returns the wall time of the
         timed region, the mean per-launch HIP-event time, the metrics buffer, the env and its action ring."""
-        env = VecMergeEnv(E, N, env_id=args.env_id, config=cfg, device=dev, first_env=first_env, **kw)
+        # per-agent outputs the rollout loop does not consume (SURVEY 8d counts none of them in B_alg) are not requested:
+        # vehicle positions / speeds for the evaluation plots, the action mask (masking is off in v1), the crashed plane
+        env = VecMergeEnv(E, N, env_id=args.env_id, config=cfg, device=dev, first_env=first_env,
+                          skip_outputs=() if args.all_outputs else ("agents_info", "action_mask", "crashed"), **kw)
         if os.environ.get("MM_BENCH_NO_METRICS"):  # tuning experiment: no in-kernel metric accumulation
             metrics = torch.zeros(8, dtype=torch.float64, device=dev)
         else:

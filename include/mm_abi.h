@@ -350,6 +350,26 @@ int32_t mm_policy_act(const float *obs, int64_t n, int32_t n_s, const float *W1,
  */
 int32_t mm_math_eval(int32_t fn, int32_t n, const double *x, const double *x2, double *y, MMStream stream);
 
+/*
+ * Diagnostics: the geometric building blocks of the step kernel on stand-alone inputs, one row per item, so that the
+ * reference's unit tables (tests/golden/units.npz: utils.py:90-121 rotated_rectangles_intersect, road.py:51-109
+ * get_closest_lane_index / next_lane, lane.py:61-95, controller.py:146-187,327-337) run against the DEVICE functions
+ * themselves and not only through trajectories.  in / out: DEV double rows (integers and flags as doubles).
+ *   MM_GEOM_POSE   in [n][3] x, y, heading          -> out [n][19] closest lane, next_lane of lane 0..5, is_reachable_from
+ *                                                       of lane 0..5, after_end of lane 0..5
+ *   MM_GEOM_STEER  in [n][5] x, y, heading, speed, target lane -> out [n][1] steering_control
+ *   MM_GEOM_RECT   in [n][6] x1, y1, h1, x2, y2, h2 -> out [n][4]: [0] vehicle 1 collides with a vehicle at pose 2 AS THE
+ *                  STEP KERNEL DECIDES IT (norm <= LENGTH pre-check of kinematics.py:205, then the kernel's own exact
+ *                  early-out boxes_may_touch, then the 9-point test), [1] the same against an Obstacle (2 x 2, heading 0) at
+ *                  (x2, y2), [2] / [3] the 9-point test alone (= rotated_rectangles_intersect) for the two cases
+ *   MM_GEOM_SPEED_INDEX in [n][1] speed -> out [n][1] MDPVehicle.speed_to_index
+ */
+#define MM_GEOM_POSE 0
+#define MM_GEOM_STEER 1
+#define MM_GEOM_RECT 2
+#define MM_GEOM_SPEED_INDEX 3
+int32_t mm_geom_eval(int32_t fn, int32_t n, const double *in, double *out, MMStream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,9 @@
 #define MM_QP_RELTOL 1e-6
 #define MM_QP_FEASTOL 1e-7
 #define MM_QP_STEP 0.99
+/* dres = sqrt(v) <= MM_QP_FEASTOL  <=>  v <= MM_QP_FEASTOL_SQ: the largest double whose correctly rounded square root is
+ * <= 1e-7 (sqrt is monotone; found by stepping ulps around 1e-14, tools/gen_math_consts.py).  Saves the square root. */
+#define MM_QP_FEASTOL_SQ 0x1.6849b86a12b9bp-47
 
 /* a / b for several a with one b: R = MM_QP_RCP(b) once, then MM_QP_DIVR(a, b, R) == a / b bit for bit */
 #ifndef MM_QP_RCP
@@ -163,12 +166,16 @@ MMM_FN int mm_qp_start(MMQpState *q, double a, double h0, double h1, double h2, 
   double z0 = q->h0, z1 = q->h1, z2 = q->h2, z3 = q->h3;
   mm_qp_solve(&kkt, m4, &x0, &x2, &z0, &z1, &z2, &z3);
   double s0 = -z0, s1 = -z1, s2 = -z2, s3 = -z3;
-  double nrm = sqrt(mm_qp_dot(s0, s0, s1, s1, s2, s2, s3, s3, m4));
+  /* "if ts >= -1e-8 * max(nrm, 1.0)": the right-hand side is <= -1e-8 whatever the norm is, so ts >= 0 (some s_k <= 0, the
+   * common case) settles the test without the norm and its square root */
   const double ts = mm_qp_maxneg(s0, s1, s2, s3, m4);
-  if (ts >= -1e-8 * fmax(nrm, 1.0)) { const double sh = 1.0 + ts; s0 = s0 + sh; s1 = s1 + sh; s2 = s2 + sh; s3 = s3 + sh; }
-  nrm = sqrt(mm_qp_dot(z0, z0, z1, z1, z2, z2, z3, z3, m4));
+  int shift = ts >= 0.0;
+  if (!shift) shift = ts >= -1e-8 * fmax(sqrt(mm_qp_dot(s0, s0, s1, s1, s2, s2, s3, s3, m4)), 1.0);
+  if (shift) { const double sh = 1.0 + ts; s0 = s0 + sh; s1 = s1 + sh; s2 = s2 + sh; s3 = s3 + sh; }
   const double tz = mm_qp_maxneg(z0, z1, z2, z3, m4);
-  if (tz >= -1e-8 * fmax(nrm, 1.0)) { const double sh = 1.0 + tz; z0 = z0 + sh; z1 = z1 + sh; z2 = z2 + sh; z3 = z3 + sh; }
+  shift = tz >= 0.0;
+  if (!shift) shift = tz >= -1e-8 * fmax(sqrt(mm_qp_dot(z0, z0, z1, z1, z2, z2, z3, z3, m4)), 1.0);
+  if (shift) { const double sh = 1.0 + tz; z0 = z0 + sh; z1 = z1 + sh; z2 = z2 + sh; z3 = z3 + sh; }
   q->x0 = x0; q->x2 = x2;
   q->s0 = s0; q->s1 = s1; q->s2 = s2; q->s3 = s3; q->z0 = z0; q->z1 = z1; q->z2 = z2; q->z3 = z3;
   q->gap = mm_qp_dot(s0, z0, s1, z1, s2, z2, s3, z3, m4);
@@ -198,7 +205,7 @@ MMM_FN int mm_qp_top(const MMQpState *q, MMQpRes *r) {
   }
   rx0 = rx0 + t;
   rx2 = rx2 + u;
-  const double resx = sqrt((0.0 + rx0 * rx0) + rx2 * rx2);
+  const int dres_ok = ((0.0 + rx0 * rx0) + rx2 * rx2) <= MM_QP_FEASTOL_SQ;  /* dres = resx / resx0 = sqrt(.) / 1 <= feastol */
   r->rx0 = rx0; r->rx2 = rx2; r->rz0 = rz0; r->rz1 = rz1; r->rz2 = rz2; r->rz3 = rz3;
   const double resz = sqrt(mm_qp_dot(rz0, rz0, rz1, rz1, rz2, rz2, rz3, rz3, m4));
   const double pcost = f0, dcost = f0 + mm_qp_dot(q->z0, rz0, q->z1, rz1, q->z2, rz2, q->z3, rz3, m4) - gap;
@@ -206,8 +213,8 @@ MMM_FN int mm_qp_top(const MMQpState *q, MMQpRes *r) {
   double relgap = 0.0;
   if (pcost < 0.0) { relgap = gap / -pcost; have_rel = 1; }
   else if (dcost > 0.0) { relgap = gap / dcost; have_rel = 1; }
-  const double pres = resz / q->resz0, dres = resx / 1.0;
-  const int met = pres <= MM_QP_FEASTOL && dres <= MM_QP_FEASTOL && (gap <= MM_QP_ABSTOL || (have_rel && relgap <= MM_QP_RELTOL));
+  const double pres = resz / q->resz0;
+  const int met = pres <= MM_QP_FEASTOL && dres_ok && (gap <= MM_QP_ABSTOL || (have_rel && relgap <= MM_QP_RELTOL));
   if (q->iters == MM_QP_MAXITERS) return 2;  /* coneqp: the cap wins over a test met in the same iteration */
   return met ? 1 : 0;
 }

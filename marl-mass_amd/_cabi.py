@@ -58,6 +58,9 @@ class MMConfig(C.Structure):
                 ("traffic_density", C.c_int32), ("mixed_traffic", C.c_int32), ("num_cav", C.c_int32), ("reserved1", C.c_int32)]
 
 
+GEOM_POSE, GEOM_STEER, GEOM_RECT, GEOM_SPEED_INDEX = 0, 1, 2, 3  # mm_geom_eval functions (include/mm_abi.h)
+
+
 class MMStepOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "obs", "reward", "done", "agents_rewards", "regional_rewards", "agents_dones", "agents_info",
@@ -179,7 +182,7 @@ class CLib(object):
     SYMBOLS = ["mm_abi_version", "mm_state_layout", "mm_create", "mm_destroy", "mm_set_config",
                "mm_reset", "mm_init_from_kinematics", "mm_observe", "mm_step", "mm_shield_qp",
                "mm_set_metrics_buffer", "mm_last_error", "mm_math_eval", "mm_shield_actions", "mm_sample_actions",
-               "mm_policy_act", "mm_poll_errors"]
+               "mm_policy_act", "mm_poll_errors", "mm_geom_eval"]
 
     def __init__(self, path):
         if not os.path.exists(path):
@@ -202,6 +205,7 @@ class CLib(object):
         lib.mm_set_metrics_buffer.argtypes = [vp, vp]
         lib.mm_last_error.argtypes = [vp]
         lib.mm_math_eval.argtypes = [i32, i32, vp, vp, vp, vp]
+        lib.mm_geom_eval.argtypes = [i32, i32, vp, vp, vp]
         lib.mm_shield_actions.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         lib.mm_sample_actions.argtypes = [vp, i64, i32, u64, vp, vp, vp]
         lib.mm_policy_act.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, i32, i32, u64, vp, vp, vp, vp]

@@ -117,7 +117,7 @@ class MergeEnvCompat(object):
         try:
             self.reset()  # abstract.py:86 (the constructor already resets)
         except NotImplementedError:
-            # default configs ask for mixed traffic (HDVs), which this engine does not simulate yet:
+            # a configuration the constructor's reset cannot serve yet (e.g. traffic_type "hdv": no controlled vehicle):
             # stay un-initialised until the caller has written env.config[...] (run_mappo.py:145-171)
             # and calls reset(); step() before that raises like abstract.py:454-455.
             self.road, self.controlled_vehicles = None, []

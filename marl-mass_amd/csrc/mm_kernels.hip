@@ -1,10 +1,11 @@
 // mm_kernels.hip -- fused env.step / reset / observe kernels + the C ABI of include/mm_abi.h.
 //
 // Mapping (CDNA4, wave64): one LANE per vehicle, the G = pow2 >= N lanes of an env are contiguous
-// in a wave ("env group"), 64/G envs per wave, 256-thread blocks.  All cross-vehicle reads of an
-// env (neighbour search, collision, observation, rewards, shield) are DPP / bpermute exchanges
-// inside the group: no inter-workgroup traffic.  LDS holds per-thread "cold slots" (register
-// relief, no sharing) and, after one barrier, the transposed observation rows.  One launch = one
+// in a wave ("env group"), 64/G envs per wave, ONE wave per workgroup (64 threads; no s_barrier anywhere in
+// the step kernel).  All cross-vehicle reads of an env (neighbour search, collision, observation, rewards,
+// shield) happen inside the group -- DPP row permutations, ds_bpermute, or an LDS mailbox the owner posts
+// and its partners read by address: no inter-workgroup traffic.  LDS holds per-thread "cold slots"
+// (register relief), those mailboxes and, at the end, the transposed observation rows.  One launch = one
 // env.step for every env: 3 simulation sub-steps + rewards/info + optional re-spawn + observation.
 //
 // Sub-step structure (reference: abstract.py:512-532, road.py:269-292):
@@ -2441,6 +2442,43 @@ extern "C" int32_t mm_math_eval(int32_t fn, int32_t n, const double *x, const do
                                 MMStream stream) {
   if (fn < 0 || fn > 9 || n <= 0) return MM_ERR_INVALID_ARG;
   hipLaunchKernelGGL(math_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, fn, n, x, x2, y);
+  return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_DEVICE;
+}
+
+// diagnostics: the step kernel's geometric device functions on stand-alone rows (include/mm_abi.h: mm_geom_eval)
+__global__ void geom_kernel(int fn, int n, const double *__restrict__ in, double *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (fn == MM_GEOM_POSE) {
+    const double x = in[i * 3 + 0], y = in[i * 3 + 1], h = in[i * 3 + 2];
+    double *o = out + (long long)i * 19;
+    o[0] = closest_lane(x, y, h);
+    for (int l = 0; l < 6; l++) {
+      o[1 + l] = next_lane(l, x, y);
+      o[7 + l] = lane_reachable(l, x, y) ? 1.0 : 0.0;
+      o[13 + l] = lane_after_end(l, x) ? 1.0 : 0.0;
+    }
+  } else if (fn == MM_GEOM_STEER) {
+    const double *r = in + (long long)i * 5;
+    out[i] = steering_control(r[0], r[1], r[2], r[3], (int)r[4]);
+  } else if (fn == MM_GEOM_RECT) {
+    const double *r = in + (long long)i * 6;
+    double *o = out + (long long)i * 4;
+    const double dx = r[3] - r[0], dy = r[4] - r[1];
+    const bool near = !((dx * dx + dy * dy) > kU5);  // the step kernel's form of `norm > LENGTH`
+    const bool t_v = near && boxes_may_touch(dx, dy, r[2], r[5], 0.9 * kVehLength / 2, 0.9 * kVehWidth / 2);
+    const bool t_o = near && boxes_may_touch(dx, dy, r[2], 0.0, 0.9 * 2.0 / 2, 0.9 * 2.0 / 2);
+    const bool full_v = rects_intersect(r[0], r[1], r[2], r[3], r[4], kVehLength, kVehWidth, r[5]);
+    const bool full_o = rects_intersect(r[0], r[1], r[2], r[3], r[4], 2.0, 2.0, 0.0);
+    o[0] = (t_v && full_v) ? 1.0 : 0.0; o[1] = (t_o && full_o) ? 1.0 : 0.0;
+    o[2] = full_v ? 1.0 : 0.0; o[3] = full_o ? 1.0 : 0.0;
+  } else {
+    out[i] = speed_to_index(in[i]);
+  }
+}
+extern "C" int32_t mm_geom_eval(int32_t fn, int32_t n, const double *in, double *out, MMStream stream) {
+  if (fn < MM_GEOM_POSE || fn > MM_GEOM_SPEED_INDEX || n <= 0 || !in || !out) return MM_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(geom_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, fn, n, in, out);
   return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_DEVICE;
 }
 

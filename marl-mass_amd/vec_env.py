@@ -31,7 +31,7 @@ class BatchedMergeEnv(object):
 
     def __init__(self, clib, E, N, env_id="merge-multi-agent-v1", config=None, device="cpu",
                  cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0, first_env=0,
-                 trace=False, debug_flags=0, n_hdv=0, qp_solver="exact", draw_counts=False, num_cav=0):
+                 trace=False, debug_flags=0, n_hdv=0, qp_solver="exact", draw_counts=False, num_cav=0, skip_outputs=()):
         self.clib, self.E, self.N = clib, int(E), int(N)
         self.env_id = env_id
         self.device = torch.device(device)
@@ -76,9 +76,18 @@ class BatchedMergeEnv(object):
             "traffic_speed": z(self.E), "min_headway": z(self.E), "merge_percent": z(self.E),
             "action_mask": z(self.E, self.N, 5, dtype=torch.uint8),
         }
+        # skip_outputs: per-agent planes a caller does not consume -- "agents_info" (24 B/agent), "action_mask" (5 B), "crashed"
+        # (1 B): the kernel does not write an output whose MMStepOut pointer is NULL (mm_abi.h); step()'s info dict then has
+        # no such key.  The reference's info always carries them, so the default (and MergeEnvCompat) keeps everything.
+        for k in skip_outputs:
+            if k not in ("agents_info", "action_mask", "crashed"):
+                raise ValueError("only agents_info / action_mask / crashed may be skipped, got %r" % (k,))
+            if k == "action_mask" and self.config.get("action_masking"):
+                raise ValueError("action_masking is on: the mask is part of the step's result")
+            del self.out[k]
         self.trace = z(3, len(abi.T_PLANES), self.E, self.N) if trace else None
         self.metrics = None
-        self._step_out = abi.MMStepOut()
+        self._step_out = abi.MMStepOut()  # (zero-initialised: a skipped output stays NULL)
         self._step_out.obs = self.obs.data_ptr()
         for k, t in self.out.items():
             setattr(self._step_out, k, t.data_ptr())

@@ -1850,6 +1850,40 @@ void orc_batch_rect(int32_t n, const double *rect /*[n][6]*/, uint8_t *hit, uint
   }
 }
 
+/* include/mm_abi.h mm_geom_eval: the oracle's own functions on the same row layouts (host pointers) */
+int32_t mm_geom_eval(int32_t fn, int32_t n, const double *in, double *out, MMStream stream) {
+  (void)stream;
+  if (fn < MM_GEOM_POSE || fn > MM_GEOM_SPEED_INDEX || n <= 0 || !in || !out) return MM_ERR_INVALID_ARG;
+  for (int i = 0; i < n; i++) {
+    if (fn == MM_GEOM_POSE) {
+      const double x = in[i * 3 + 0], y = in[i * 3 + 1], h = in[i * 3 + 2];
+      double *o = out + (int64_t)i * 19;
+      o[0] = closest_lane(x, y, h);
+      for (int l = 0; l < 6; l++) {
+        o[1 + l] = next_lane(l, x, y);
+        o[7 + l] = lane_is_reachable_from(l, x, y);
+        o[13 + l] = lane_after_end(l, x, y);
+      }
+    } else if (fn == MM_GEOM_STEER) {
+      const double *r = in + (int64_t)i * 5;
+      out[i] = orc_steering_control(r[0], r[1], r[2], r[3], (int32_t)r[4]);
+    } else if (fn == MM_GEOM_RECT) {
+      const double *r = in + (int64_t)i * 6;
+      double *o = out + (int64_t)i * 4;
+      Veh a;
+      memset(&a, 0, sizeof a);
+      a.x = r[0]; a.y = r[1]; a.heading = r[2];
+      o[0] = is_colliding(&a, r[3], r[4], VEH_LENGTH, VEH_WIDTH, r[5]);   /* kinematics.py:202-209: pre-check + 9-point test */
+      o[1] = is_colliding(&a, r[3], r[4], OBST_LENGTH, OBST_WIDTH, 0.0);
+      o[2] = rotated_rectangles_intersect(r[0], r[1], 0.9 * VEH_LENGTH, 0.9 * VEH_WIDTH, r[2], r[3], r[4], 0.9 * VEH_LENGTH, 0.9 * VEH_WIDTH, r[5]);
+      o[3] = rotated_rectangles_intersect(r[0], r[1], 0.9 * VEH_LENGTH, 0.9 * VEH_WIDTH, r[2], r[3], r[4], 0.9 * OBST_LENGTH, 0.9 * OBST_WIDTH, 0.0);
+    } else {
+      out[i] = speed_to_index(in[i]);
+    }
+  }
+  return MM_OK;
+}
+
 /* thread control for the cpu_baseline leg of bench.py (OpenMP over envs) */
 #ifdef _OPENMP
 #include <omp.h>

@@ -1,7 +1,9 @@
 """Replay of the reference's golden episode tapes (tests/golden/ep_*.npz) on any backend.
 
-The tapes were produced by tools/gen_golden.py from the reference itself; shield tapes carry the
-label "reference assembly + exact-KKT solve" (cvxopt is unavailable in the image).
+The tapes were produced by tools/gen_golden.py from the reference itself.  cvxopt is unavailable in the image, so a
+stand-in answered `solvers.qp` while the reference ran; each shield tape's meta says which one (`qp_solver`): the
+closed-form exact-KKT solve (ep_ / mx_ / sc_ / ... tapes) or the restatement of cvxopt's coneqp (the 13 ipm_* tapes) --
+is_ipm(meta) below -- and every tape also carries the other solver's answer to the same (G, h) as `qp_x_alt`.
 """
 import glob
 import json

@@ -116,3 +116,27 @@ def test_create_rejects_bad_sizes_hip():
     for E, N, over in ((0, 8, {}), (4, 0, {}), (4, 13, {}), (4, 8, {"n_hdv": 8}), (4, 8, {"abi_version": 1}), (4, 8, {"shield": 9}),
                        (4, 8, {"qp_solver": 2})):
         assert _create_rc(clib, E, N, device="cuda", **over) != 0, (E, N, over)
+
+
+def test_skipped_outputs_are_not_written_and_change_nothing_else():
+    """MMStepOut: a NULL per-agent output is not written (mm_abi.h); VecMergeEnv(skip_outputs=...) hands NULL for
+    agents_info / action_mask / crashed.  Everything else -- state, obs, the other outputs -- is what the full call gives."""
+    import torch
+    import oracle_env
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5,
+              seed=5, auto_reset=True)
+    full, lean = oracle_env.OracleEnv(32, 8, **kw), oracle_env.OracleEnv(32, 8, skip_outputs=("agents_info", "action_mask", "crashed"), **kw)
+    full.reset(); lean.reset()
+    g = torch.Generator().manual_seed(2)
+    for t in range(12):
+        a = torch.randint(0, 5, (32, 8), generator=g, dtype=torch.int32)
+        of, rf, df, inf_ = full.step(a)
+        ol, rl, dl, inl = lean.step(a)
+        assert torch.equal(full.state, lean.state) and torch.equal(of, ol) and torch.equal(rf, rl) and torch.equal(df, dl)
+        assert set(inf_) - set(inl) == {"agents_info", "action_mask", "crashed"}
+        for k in inl:
+            assert torch.equal(inf_[k].nan_to_num(), inl[k].nan_to_num()), k
+    with pytest.raises(ValueError):
+        oracle_env.OracleEnv(4, 4, skip_outputs=("reward",), **kw)
+    with pytest.raises(ValueError):  # with masking on, the mask is a result of the step
+        oracle_env.OracleEnv(4, 4, env_id="merge-multi-agent-v0", config={"action_masking": True}, skip_outputs=("action_mask",))

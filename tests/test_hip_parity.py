@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import oracle_env
-from golden_util import check_safety_layer_probes, episode_files, free_run, load_episode, replay, FLOAT_TOL
+from golden_util import GOLDEN, check_safety_layer_probes, episode_files, free_run, load_episode, replay, FLOAT_TOL
 from marl_mass_amd import VecMergeEnv, _cabi as abi
 
 pytestmark = pytest.mark.gpu
@@ -478,14 +478,24 @@ def test_ragged_batch_with_absent_slots(safety, with_hdv):
     assert torch.equal(gpu.u8.cpu(), cpu.u8) and torch.equal(gpu.f64.cpu().nan_to_num(), cpu.f64.nan_to_num())
 
 
-@pytest.mark.parametrize("name", ["ep_v1_mass_N8_s0", "mx_v1_hss_4c3h_s25", "sv_v1_mass_N8_s50"])
+@pytest.mark.parametrize("name", ["ep_v1_mass_N8_s0", "mx_v1_hss_4c3h_s25", "sv_v1_mass_N8_s50", "ipm_v1_mass_N8_s0", "ipm_v1_mass_4c3h_s25"])
 def test_compat_adapter_on_gpu_matches_golden(name):
     """The drop-in object API (MergeEnvCompat: numpy-RNG reset replay + step tuple + control profile) over the
     HIP backend, free-running on a reference tape: what a maintainer's `env = make(env_id)` swap executes."""
     from marl_mass_amd import compat
-    from golden_util import GOLDEN
+    from golden_util import is_ipm
     z, meta = load_episode(os.path.join(GOLDEN, name + ".npz"))
+    saved = (compat.CBFType.GAMMA_B, compat.CBFType.TAU, compat.CBFType.QP_SOLVER)
     compat.CBFType.GAMMA_B, compat.CBFType.TAU = meta["eta"], meta["headway_time"]
+    # what answered solvers.qp while the reference produced the tape (the adapter's default is "ipm": the ipm_* tapes run it)
+    compat.CBFType.QP_SOLVER = "ipm" if is_ipm(meta) else "exact"
+    try:
+        _compat_replay(compat, z, meta)
+    finally:
+        compat.CBFType.GAMMA_B, compat.CBFType.TAU, compat.CBFType.QP_SOLVER = saved
+
+
+def _compat_replay(compat, z, meta):
     env = compat.make(meta["env_id"], store_profile=True)
     env.config.update({"safety_guarantee": meta["shield"], "HEADWAY_TIME": meta["headway_time"], "action_masking": False,
                        "lateral_control": meta.get("lateral_control", "steer")})
@@ -501,3 +511,46 @@ def test_compat_adapter_on_gpu_matches_golden(name):
     cp = env.control_profile()
     assert len(cp["av0"]["state_hist"]) == int(z["sub_count"].sum())
     assert abs(cp["av0"]["state_hist"][-1]["x"] - z["sub_f"][-1][0][0]) <= 1e-9
+
+
+def test_skipped_outputs_on_gpu():
+    """VecMergeEnv(skip_outputs=...): NULL MMStepOut pointers are not written by the step kernel, everything else is
+    bit-identical to the full call (what bench.py's headline line requests)."""
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5,
+              seed=5, auto_reset=True)
+    full, lean = _gpu_env(512, 8, **kw), _gpu_env(512, 8, skip_outputs=("agents_info", "action_mask", "crashed"), **kw)
+    full.reset(); lean.reset()
+    g = torch.Generator().manual_seed(2)
+    for t in range(30):
+        a = torch.randint(0, 5, (512, 8), generator=g, dtype=torch.int32).cuda()
+        of, rf, df, inf_ = full.step(a)
+        ol, rl, dl, inl = lean.step(a)
+        assert torch.equal(full.state, lean.state) and torch.equal(of, ol) and torch.equal(rf, rl) and torch.equal(df, dl)
+        assert set(inf_) - set(inl) == {"agents_info", "action_mask", "crashed"}
+        for k in inl:
+            assert torch.equal(inf_[k].nan_to_num(), inl[k].nan_to_num()), k
+
+
+def test_geom_unit_tables_on_the_device():
+    """The reference's unit tables (tests/golden/units.npz) against the DEVICE functions of the step kernel -- closest_lane
+    (with its kb0 pruning), next_lane, reachability, steering_control, speed_to_index, and the collision decision THROUGH
+    the kernel's own exact early-out boxes_may_touch -- not only through trajectories (mm_geom_eval, include/mm_abi.h)."""
+    import test_oracle_golden as tog
+    from marl_mass_amd import vec_env
+    units = np.load(os.path.join(GOLDEN, "units.npz"))
+    clib = abi.CLib(vec_env.HIP_LIB)
+    tog.check_geom_tables(clib, units, device="cuda:0")
+    # randomised near-contact sweep: the early-out never suppresses a hit the 9-point test reports, for vehicles and for
+    # the obstacle; and the device's 9-point test agrees with the oracle's (libm) on every pair that is not a knife-edge
+    rows = tog.near_contact_rows()
+    dev = tog._geom(clib, abi.GEOM_RECT, rows, 4, "cuda:0")
+    d2 = (rows[:, 3] - rows[:, 0]) ** 2 + (rows[:, 4] - rows[:, 1]) ** 2
+    pre = ~(np.sqrt(d2) > 5.0)
+    assert np.array_equal(dev[:, 0], pre & (dev[:, 2] != 0)) and np.array_equal(dev[:, 1], pre & (dev[:, 3] != 0))
+    assert dev[:, 2].sum() > 20000 and (pre & (dev[:, 2] == 0)).sum() > 20000  # both outcomes are well represented
+    oracle_env.set_math_mode(1)
+    try:
+        cpu = tog._geom(oracle_env.library(), abi.GEOM_RECT, rows, 4)
+    finally:
+        oracle_env.set_math_mode(0)
+    assert np.array_equal(dev, cpu)  # same arithmetic (mm_math) on both sides: every flag equal

@@ -135,3 +135,51 @@ def test_standalone_safety_layer(path):
     oracle_env.set_math_mode(0)
     worst, checked = check_safety_layer_probes(oracle_env.OracleEnv, path, tol=1e-10)
     print(os.path.basename(path), "checked", checked, "worst", worst)
+
+
+def _geom(clib, fn, rows, n_out, device="cpu"):
+    """mm_geom_eval (include/mm_abi.h) on a [n][k] table -> [n][n_out]."""
+    import torch
+    x = torch.as_tensor(np.ascontiguousarray(rows, dtype=np.float64), device=device)
+    out = torch.zeros(len(rows), n_out, dtype=torch.float64, device=device)
+    clib.check(clib.lib.mm_geom_eval(fn, len(rows), C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), None))
+    return out.cpu().numpy()
+
+
+def check_geom_tables(clib, units, device="cpu"):
+    """The reference's unit tables through mm_geom_eval: lane argmin / next lane / reachability / end-of-lane on the pose
+    grid, steering_control on every lane, the rotated-rectangle table, speed_to_index at its ties.  Shared by the oracle leg
+    (here) and the HIP leg (tests/test_hip_parity.py): the SAME assertions on both implementations."""
+    from marl_mass_amd import _cabi as abi
+    pose = _geom(clib, abi.GEOM_POSE, np.stack([units["pose_x"], units["pose_y"], units["pose_h"]], 1), 19, device)
+    np.testing.assert_array_equal(pose[:, 0], units["closest"])
+    np.testing.assert_array_equal(pose[:, 1:7], units["next_lane"])
+    np.testing.assert_array_equal(pose[:, 7:13], units["reachable"])
+    np.testing.assert_array_equal(pose[:, 13:19], units["after_end"])
+    st = _geom(clib, abi.GEOM_STEER, np.stack([units["sc_x"], units["sc_y"], units["sc_h"], units["sc_v"], units["sc_lane"].astype(float)], 1), 1, device)
+    np.testing.assert_allclose(st[:, 0], units["sc_steer"], rtol=0, atol=1e-9)
+    rc = _geom(clib, abi.GEOM_RECT, units["rect"], 4, device)
+    np.testing.assert_array_equal(rc[:, 2], units["rect_hit"])
+    np.testing.assert_array_equal(rc[:, 3], units["rect_hit_obstacle"])
+    d2 = (units["rect"][:, 3] - units["rect"][:, 0]) ** 2 + (units["rect"][:, 4] - units["rect"][:, 1]) ** 2
+    pre = ~(np.sqrt(d2) > 5.0)  # kinematics.py:205
+    np.testing.assert_array_equal(rc[:, 0], pre & (units["rect_hit"] != 0))       # the step's decision = pre-check AND 9-point test:
+    np.testing.assert_array_equal(rc[:, 1], pre & (units["rect_hit_obstacle"] != 0))  # no early-out may suppress a hit
+    si = _geom(clib, abi.GEOM_SPEED_INDEX, units["sti_speed"][:, None], 1, device)
+    np.testing.assert_array_equal(si[:, 0], units["sti_index"])
+
+
+def near_contact_rows(n=200000, seed=11):
+    """Random near-contacts: centre distance 1.8 .. 5.2 m in any direction, |heading| <= 1.2 rad on both boxes."""
+    rs = np.random.RandomState(seed)
+    dist, ang = rs.uniform(1.8, 5.2, n), rs.uniform(-np.pi, np.pi, n)
+    rows = np.zeros((n, 6))
+    rows[:, 0], rows[:, 1] = rs.uniform(0, 500, n), rs.uniform(-2, 12, n)
+    rows[:, 2], rows[:, 5] = rs.uniform(-1.2, 1.2, n), rs.uniform(-1.2, 1.2, n)
+    rows[:, 3], rows[:, 4] = rows[:, 0] + dist * np.cos(ang), rows[:, 1] + dist * np.sin(ang)
+    return rows
+
+
+def test_geom_tables_oracle(units):
+    oracle_env.set_math_mode(0)
+    check_geom_tables(oracle_env.library(), units)

@@ -71,3 +71,20 @@ for k in range(2, 15):  # exp: 1/k!
     emit("MMM_E%d" % k, to_double(Decimal(1) / Decimal(math.factorial(k))))
 for k in range(1, 12):  # log: 1/(2k+1)
     emit("MMM_L%d" % k, to_double(Decimal(1) / Decimal(2 * k + 1)))
+
+
+def feastol_sq():
+    """MM_QP_FEASTOL_SQ of include/mm_qp.h: the largest double v with RN(sqrt(v)) <= 1e-7 (math.sqrt is correctly rounded)."""
+    import math
+    F = 1e-7
+    v = F * F
+    while math.sqrt(v) <= F:
+        v = math.nextafter(v, math.inf)
+    while math.sqrt(v) > F:
+        v = math.nextafter(v, -math.inf)
+    assert math.sqrt(v) <= F < math.sqrt(math.nextafter(v, math.inf))
+    return v
+
+
+if __name__ == "__main__":
+    print("MM_QP_FEASTOL_SQ", feastol_sq().hex())

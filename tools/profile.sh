@@ -4,10 +4,10 @@
 # Usage: bash tools/profile.sh [extra bench.py args]
 set -eo pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/prof
+O=$R/gpurun_out/prof${PROF_TAG:+_$PROF_TAG}   # PROF_TAG=name: one output directory per profiled workload
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-fidelity-line --steps 200 --warmup 10 "$@" > "$O/bench_under_rocprof.json" 2> "$O/stats.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-fidelity-line --steps ${PROF_STEPS:-200} --warmup 10 "$@" > "$O/bench_under_rocprof.json" 2> "$O/stats.err"
 i=0
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
          "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \

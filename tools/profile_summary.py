@@ -19,7 +19,7 @@ trace = glob.glob(os.path.join(O, "stats", "**", "*kernel_trace.csv"), recursive
 if trace:
     tr = [r for r in csv.DictReader(open(trace[0])) if "step_kernel" in r["Kernel_Name"]]
     tr.sort(key=lambda r: int(r["Start_Timestamp"]))
-    last = tr[-200:]
+    last = tr[-int(os.environ.get("PROF_STEPS", "200")):]  # the timed region = the last --steps launches
     d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in last]
     out["avg_ns"] = sum(d) / len(d)
     out["timed_region"] = {"launches": len(d), "avg_ns": out["avg_ns"], "min_ns": min(d), "max_ns": max(d)}
