@@ -162,11 +162,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--envs", type=int, default=65536, help="envs PER GPU (weak scaling)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong",
+    ap.add_argument("--envs", type=int, default=None, help="envs PER GPU (weak scaling; default 65536).  Given without --total-envs / "
+                                                           "--scaling it selects weak scaling: `--envs 8192` = 8 192 envs on every GPU")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="strong (default): BASELINE's 65 536 envs in total, split over the GPUs; weak: --envs per GPU")
     ap.add_argument("--no-weak-extra", action="store_true", help="N > 1, strong scaling: skip the extra weak-scaling measurement")
-    ap.add_argument("--total-envs", type=int, default=65536, help="envs over ALL GPUs (strong scaling; BASELINE c5 = 65536 over 8)")
+    ap.add_argument("--total-envs", type=int, default=None, help="envs over ALL GPUs (strong scaling; default 65536 = BASELINE c5 over 8)")
     ap.add_argument("--qp-solver", choices=("exact", "ipm"), default="exact",
                     help="exact: closed-form KKT point (production); ipm: cvxopt's interior-point iterate (fidelity mode)")
     ap.add_argument("--no-stagger", action="store_true", help="skip the phase staggering + pre-roll (lock-stepped episodes)")
@@ -191,6 +192,10 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=400)
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
+    if args.scaling is None:  # an explicit per-GPU batch size means per-GPU work is what the caller fixes
+        args.scaling = "weak" if (args.envs is not None and args.total_envs is None) else "strong"
+    args.envs = 65536 if args.envs is None else args.envs
+    args.total_envs = 65536 if args.total_envs is None else args.total_envs
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

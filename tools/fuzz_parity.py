@@ -31,7 +31,7 @@ def draw_case(rng):
     if draw_counts:
         density = rng.choice([1, 2, 3])
         N = {1: 6, 2: 8, 3: 11}[density] + rng.choice([0, 0, 1])
-        mixed = rng.random() < 0.5
+        mixed = rng.choice([False, True, True, "av"]) if v1 else (rng.random() < 0.5)   # "av": one CAV among HDVs (v1 only)
         n_hdv = 0  # (the counts are drawn per episode)
     else:
         density, mixed = 0, False
@@ -49,12 +49,12 @@ def draw_case(rng):
            "action_masking": rng.random() < 0.3}
     if draw_counts:
         cfg["traffic_density"] = density
-        cfg["traffic_type"] = "mixed" if mixed else "cav"
-        cfg["mixed_traffic"] = mixed
+        cfg["traffic_type"] = mixed if isinstance(mixed, str) else ("mixed" if mixed else "cav")
+        cfg["mixed_traffic"] = bool(mixed)
     kw = dict(env_id="merge-multi-agent-v1" if v1 else "merge-multi-agent-v0", config=cfg,
               cbf_eta=rng.choice([0.03125, 0.03125, 0.5, 0.1]) if shielded else 0.0, cbf_tau=cfg["HEADWAY_TIME"],
               obs_f64=rng.random() < 0.5, seed=rng.randrange(1, 1 << 30), auto_reset=True, n_hdv=n_hdv,
-              qp_solver="ipm" if (shielded and rng.random() < 0.2) else "exact", trace=rng.random() < 0.3,
+              qp_solver="ipm" if (shielded and rng.random() < 0.3) else "exact", trace=rng.random() < 0.3,
               draw_counts=draw_counts)
     # (odd batch sizes: the last wave of the launch is partly empty and an env group may be the only one in its wave)
     E = rng.choice([64, 128, 256, 512, 1, 7, 37, 100, 333]) if kw["qp_solver"] == "exact" else rng.choice([32, 64, 128, 5, 45])
