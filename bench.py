@@ -243,8 +243,9 @@ def main():
         timed region, the mean per-launch HIP-event time, the metrics buffer, the env and its action ring."""
         # per-agent outputs the rollout loop does not consume (SURVEY 8d counts none of them in B_alg) are not requested:
         # vehicle positions / speeds for the evaluation plots, the action mask (masking is off in v1), the crashed plane
-        env = VecMergeEnv(E, N, env_id=args.env_id, config=cfg, device=dev, first_env=first_env,
-                          skip_outputs=() if args.all_outputs else ("agents_info", "action_mask", "crashed"), **kw)
+        masking = dict(abi.default_env_config(args.env_id), **cfg).get("action_masking")  # (v0's default masks: the mask is a result)
+        skip = () if args.all_outputs else (("agents_info", "crashed") if masking else ("agents_info", "action_mask", "crashed"))
+        env = VecMergeEnv(E, N, env_id=args.env_id, config=cfg, device=dev, first_env=first_env, skip_outputs=skip, **kw)
         if os.environ.get("MM_BENCH_NO_METRICS"):  # tuning experiment: no in-kernel metric accumulation
             metrics = torch.zeros(8, dtype=torch.float64, device=dev)
         else:

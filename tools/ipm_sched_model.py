@@ -79,40 +79,53 @@ def analyse(path, E, N, steps, G=8):
         total += 1
         capped += 0 if opt else 1
     envs_per_wave = 64 // G
-    # per (env, sub): chain length in iterations (longest path) and per-rank iterations
-    chain = {}
-    depth_hist = collections.Counter()
-    for key, qs in per.items():
-        done_at = {}
-        depth = {}
-        for (i, r, it, opt, rows, dol, doa) in sorted(qs, key=lambda q: q[1]):
-            start = max([done_at.get(d, 0) for d in (dol, doa) if d >= 0] + [0])
-            dd = max([depth.get(d, 0) for d in (dol, doa) if d >= 0] + [0])
-            done_at[i] = start + it + 1   # +1: the trip in which the result is posted and the dependants set up
-            depth[i] = dd + 1
-        chain[key] = max(done_at.values()) if done_at else 0
-        depth_hist[max(depth.values()) if depth else 0] += 1
     n_sub = max(s for (_, s) in per) + 1
     waves = E // envs_per_wave
-    lit = chn = 0
+
+    def chained(extra, cap=None):
+        """Trips per wave and policy step when a QP starts as soon as the decisions it reads are final.  extra = 1: the
+        follower starts in the trip AFTER its input stopped; extra = 0 (what the kernel does): in the same trip.
+        cap: pretend no QP runs longer than `cap` iterations (isolates what the iteration-capped QPs cost)."""
+        tot = 0
+        depth_hist.clear()
+        for w in range(waves):
+            for s in range(n_sub):
+                worst = 0
+                for e in range(w * envs_per_wave, (w + 1) * envs_per_wave):
+                    done_at, depth = {}, {}
+                    for (i, r, it, opt, rows, dol, doa) in sorted(per.get((e, s), ()), key=lambda q: q[1]):
+                        it = min(it, cap) if cap else it
+                        start = max([done_at.get(d, 0) for d in (dol, doa) if d >= 0] + [0])
+                        done_at[i] = start + it + extra
+                        depth[i] = max([depth.get(d, 0) for d in (dol, doa) if d >= 0] + [0]) + 1
+                    if done_at:
+                        worst = max(worst, max(done_at.values()) + (1 - extra))  # (+ the trip of the last stopping test)
+                        depth_hist[max(depth.values())] += 1
+                tot += worst
+        return tot / (waves * steps)
+
+    depth_hist = collections.Counter()
+    lit = 0
     for w in range(waves):
-        envs = range(w * envs_per_wave, (w + 1) * envs_per_wave)
         for s in range(n_sub):
             # literal: stage r lasts max over the wave's envs of that rank's iterations
             stage = collections.defaultdict(int)
-            for e in envs:
+            for e in range(w * envs_per_wave, (w + 1) * envs_per_wave):
                 for (i, r, it, *_rest) in per.get((e, s), ()):
                     stage[r] = max(stage[r], it + 1)
             lit += sum(stage.values())
-            chn += max([chain.get((e, s), 0) for e in envs] + [0])
+    trips = {"literal_sweep": lit / (waves * steps), "chained_next_trip": chained(1), "chained_same_trip": chained(0),
+             "chained_same_trip_if_no_qp_ran_past_10_iterations": chained(0, cap=10)}
     lane_iters = sum(k * v for k, v in hist.items())
+    trips["ideal_packed"] = lane_iters / 64 / (waves * steps)
     out = {
         "workload": "%d envs x %d CAVs, MASS, ipm, %d policy steps (stationary batch)" % (E, N, steps),
         "qps": total, "qps_per_env_step": total / (E * steps), "capped_share": capped / total,
         "iters_mean": lane_iters / total, "iters_hist": {str(k): hist[k] for k in sorted(hist)},
         "chain_depth_hist_per_env_substep": {str(k): depth_hist[k] for k in sorted(depth_hist)},
-        "trips_per_wave_step": {"literal": lit / (waves * steps), "chained": chn / (waves * steps),
-                                "ideal_packed": lane_iters / 64 / (waves * steps)},
+        "trips_per_wave_step": trips,
+        "reading": "a trip = one execution of the interior-point body by a wave of 8 envs; the kernel runs chained_same_trip; "
+                   "ideal_packed = lane-iterations / 64 is what perfect packing without dependencies would need",
     }
     return out
 
