@@ -206,6 +206,14 @@ MM_DEV void store_veh(const DevState &st, long long i, const Veh &v, bool with_s
 // tracks the scaled-down reference angle (KP_STEER 20, STEER_TARGET_RF 0.125)
 MM_DEV double steer_vel_command(double steering_ref, double sang) { return 20 * (steering_ref * 0.125 - sang); }
 // st_t: 1/2 tan of the steering command (see steering_control; NaN: not known)
+// STEER = false (general kernels): the steering command is left to ONE steering_control call for CAVs and HDVs together,
+// after the HDVs have decided their target lanes (steer_lanes below); steering does not enter anything in between
+MM_DEV void steer_lane(Veh &v, bool sv, double &st_t) {
+  double steer = steering_control(v.x, v.y, v.h, v.v, v.tlane, st_t);
+  if (sv) { steer = steer_vel_command(steer, v.sang); st_t = __builtin_nan(""); }
+  v.act_steer = clipd(steer, -kPi / 3, kPi / 3);
+}
+template <bool STEER = true>
 MM_DEV void controlled_act(Veh &v, int action, bool sv, double &st_t) {
   if (lane_after_end(v.tlane, v.x)) v.tlane = next_lane(v.tlane, v.x, v.y);  // follow_road :136-144
   if (action == 2 || action == 0) {
@@ -214,10 +222,8 @@ MM_DEV void controlled_act(Veh &v, int action, bool sv, double &st_t) {
     if (lane_road(v.tlane) == 1) cand = (action == 2) ? MM_LANE_BC1 : MM_LANE_BC0;
     if (lane_reachable(cand, v.x, v.y)) v.tlane = cand;
   }
-  double steer = steering_control(v.x, v.y, v.h, v.v, v.tlane, st_t);
-  if (sv) { steer = steer_vel_command(steer, v.sang); st_t = __builtin_nan(""); }
   v.act_acc = (1 / kTauA) * (v.tspeed - v.v);  // speed_control :189-197
-  v.act_steer = clipd(steer, -kPi / 3, kPi / 3);
+  if constexpr (STEER) steer_lane(v, sv, st_t);
 }
 // The high-level act of a policy step: action_type.act -> MDPLCVehicle.act / MDPVehicle.act /
 // ControlledVehicle.act (safe_controller.py:63-66, controller.py:293-311, :90-125).  Road.act()
@@ -563,15 +569,20 @@ struct Body {  // what IDM reads of a vehicle / object
   bool present, is_object;
   double x, y, h, v, tspeed;
   int lane;
+  // posted once by the vehicle itself instead of being re-evaluated by every (ego, partner) pair: sin / cos of its heading
+  // (the step kernel carries them along: the same mmm_sincos of the same value) and its lateral offset of the sine lane kb0,
+  // kSineAmp * sin(kSinePuls * (x - 220) + kSinePhase) (only read when the ego's lane is kb0)
+  double sh, ch, koff;
 };
 MM_DEV double desired_gap(const Body &ego, const Body &front) {  // behavior.py:141-156 (projected)
-  const double ab = 15.0;  // -COMFORT_ACC_MAX * COMFORT_ACC_MIN
-  double es, ec, fs, fc;
-  mmm_sincos(ego.h, &es, &ec);
-  mmm_sincos(front.h, &fs, &fc);
+  constexpr double ab = 15.0;  // -COMFORT_ACC_MAX * COMFORT_ACC_MIN
+  const double es = ego.sh, ec = ego.ch, fs = front.sh, fc = front.ch;
   const double evx = ego.v * ec, evy = ego.v * es, fvx = front.v * fc, fvy = front.v * fs;
   const double dv = (evx - fvx) * ec + (evy - fvy) * es;
-  return 10.0 + ego.v * 1.5 + ego.v * dv / (2 * sqrt(ab));
+  // (the divisor 2 sqrt(15) is a compile-time constant: Markstein's constant-divisor form, bit-identical to the division)
+  constexpr double den = 0x1.efbdeb14f4edap+2;  // 2 * np.sqrt(15.0) = 7.745966692414834 (sqrt correctly rounded, * 2 exact)
+  static_assert(den * den > 4 * ab * (1 - 1e-15) && den * den < 4 * ab * (1 + 1e-15), "2 sqrt(ab)");
+  return 10.0 + ego.v * 1.5 + div_c(ego.v * dv, den, 1.0 / den);
 }
 MM_DEV double idm_acceleration(const Body &ego, const Body &front) {  // behavior.py:111-139
   if (!ego.present || ego.is_object) return 0;
@@ -587,16 +598,27 @@ MM_DEV double idm_acceleration(const Body &ego, const Body &front) {  // behavio
   }
   return acc;
 }
-// one candidate of road.neighbour_vehicles(lane) (road.py:352-381): keeps the running front / rear.
-// idx = creation index (obstacle: 99, it is scanned last); ties follow the reference's loop order.
-MM_DEV void neighbour_update(int lane, double s_me, const Body &b, int idx, Body &front, double &s_front, int &i_front,
-                             Body &rear, double &s_rear, int &i_rear) {
-  if (!b.present) return;
-  double s_v = b.x - lane_sx(lane), lat = b.y - lane_sy(lane);
-  if (lane == MM_LANE_KB0) lat = lat - kSineAmp * mmm_sin(kSinePuls * s_v + kSinePhase);
-  if (!(fabs(lat) <= kLaneWidth / 2 + 1 && (-kVehLength <= s_v && s_v < lane_len(lane) + kVehLength))) return;
-  if (s_me <= s_v && (i_front < 0 || s_v < s_front || (s_v == s_front && idx > i_front))) { s_front = s_v; i_front = idx; front = b; }
-  if (s_v < s_me && (i_rear < 0 || s_v > s_rear || (s_v == s_rear && idx < i_rear))) { s_rear = s_v; i_rear = idx; rear = b; }
+// one candidate of road.neighbour_vehicles(lane) (road.py:352-381): keeps the running front / rear by INDEX (creation index;
+// obstacle: 99, it is scanned last); ties follow the reference's loop order.  The chosen bodies are gathered from their owners
+// after the scan (Body copies under four conditions per candidate were 1.3 k instructions of the mixed-traffic kernels).
+struct NbSel {
+  double s_front, s_rear;
+  int i_front, i_rear;  // -1: none
+};
+// the scanned lane's frame, evaluated once per ego instead of once per candidate
+struct LaneFrame {
+  double sx, sy, s_hi;  // lane start, lane_len + LENGTH
+  bool sine;            // kb0: the lateral offset follows the sine
+};
+MM_DEV LaneFrame lane_frame(int lane) { return {lane_sx(lane), lane_sy(lane), lane_len(lane) + kVehLength, lane == MM_LANE_KB0}; }
+MM_DEV void neighbour_update(const LaneFrame &lf, double s_me, bool present, double bx, double by, double bkoff, int idx, NbSel &n) {
+  double s_v = bx - lf.sx, lat = by - lf.sy;
+  if (lf.sine) lat = lat - bkoff;  // (= kSineAmp * sin(kSinePuls * s_v + kSinePhase), posted by the body's owner)
+  const bool on = present && fabs(lat) <= kLaneWidth / 2 + 1 && -kVehLength <= s_v && s_v < lf.s_hi;
+  const bool fr = on && s_me <= s_v && (n.i_front < 0 || s_v < n.s_front || (s_v == n.s_front && idx > n.i_front));
+  const bool rr = on && s_v < s_me && (n.i_rear < 0 || s_v > n.s_rear || (s_v == n.s_rear && idx < n.i_rear));
+  n.s_front = fr ? s_v : n.s_front; n.i_front = fr ? idx : n.i_front;
+  n.s_rear = rr ? s_v : n.s_rear; n.i_rear = rr ? idx : n.i_rear;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -985,8 +1007,9 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
       if (time % c.nsub == 0) hl_act<KIND>(v, action);  // action_type.act abstract.py:516-519
     }
     const int tl_pre = v.tlane;  // what an HDV acting before this vehicle still sees
-    if (live && !hdv) controlled_act(v, -1, sv, st_t);  // road.act road.py:269-278
+    if (live && !hdv) controlled_act<!MIXED>(v, -1, sv, st_t);  // road.act road.py:269-278 (general kernels: steering below)
     s_cold[C_TSPEED][tid] = v.tspeed;
+    if constexpr (MIXED) { STAMP(1); }  // (general kernels: "act" = the CAVs' part up to here; slots 3 / 4 / 5 split the HDVs' part)
     if constexpr (MIXED) {
       // ---------------- IDMVehicle.act for the HDVs (behavior.py:74-100) -------------------------
       // Positions do not move during Road.act, so each HDV scans its neighbours in parallel.  The one
@@ -995,11 +1018,17 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
       // value of the others; HDV decisions ahead feed HDVs behind -> small fixed point on tl_post.
       if (__any(hdv && live)) {
         const bool acting = hdv && live && !v.crashed;
-        Body self = {true, false, v.x, v.y, v.h, v.v, v.tspeed, v.lane};
+        // the sine-lane offset of my position, for the HDVs that scan lane kb0 (an ego's own lane only: the side lane of a
+        // lane change is bc0 / bc1); one sine per vehicle instead of one per (ego, partner) pair
+        double koff = 0.0, koff_obst = 0.0;
+        if (__any(acting && v.lane == MM_LANE_KB0)) {
+          koff = kSineAmp * mmm_sin(kSinePuls * (v.x - lane_sx(MM_LANE_KB0)) + kSinePhase);
+          koff_obst = kSineAmp * mmm_sin(kSinePuls * (kObstX - lane_sx(MM_LANE_KB0)) + kSinePhase);
+        }
+        Body self = {true, false, v.x, v.y, v.h, v.v, v.tspeed, v.lane, spsi, cpsi, koff};
         const double s_me = v.x - lane_sx(v.lane);
-        Body front0 = {}, rear0 = {};
-        double sf0 = 0, sr0 = 0;
-        int if0 = -1, ir0 = -1;
+        NbSel n0 = {0, 0, -1, -1}, n1 = {0, 0, -1, -1};  // own lane; the lane MOBIL considers
+        const LaneFrame lf0 = lane_frame(v.lane);
         if (acting && lane_after_end(v.tlane, v.x)) v.tlane = next_lane(v.tlane, v.x, v.y);  // follow_road
         const int my_tl = v.tlane;
         const bool lc_branch = v.lane != my_tl;  // a lane change is under way (:191)
@@ -1009,44 +1038,54 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
         const bool try_mobil = acting && timer_due && side >= 0 && lane_reachable(side < 0 ? 0 : side, v.x, v.y);
         const int sl = side < 0 ? 0 : side;
         const double s_side = v.x - lane_sx(sl);
-        Body front1 = {}, rear1 = {};
-        double sf1 = 0, sr1 = 0;
-        int if1 = -1, ir1 = -1;
+        const LaneFrame lf1 = lane_frame(sl);
         unsigned abort_mask = 0;  // partners that would make me abort IF they target my target lane
-        unsigned tl_all = 0;      // 3 bits per partner: its pre / post target lane is exchanged below
-        (void)tl_all;
         for_partners<G>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
           const int p = a ^ m;
-          Body b;
-          b.present = dppx_i<m>((int)live) != 0;
-          b.is_object = false;
-          b.x = dppx_d<m>(v.x); b.y = dppx_d<m>(v.y); b.h = dppx_d<m>(v.h); b.v = dppx_d<m>(v.v);
-          b.tspeed = dppx_d<m>(v.tspeed);
-          b.lane = dppx_i<m>(v.lane);
+          const bool bp = dppx_i<m>((int)live) != 0;
+          const double bx = dppx_d<m>(v.x), by = dppx_d<m>(v.y), bk = dppx_d<m>(koff);
           if (acting) {
-            neighbour_update(v.lane, s_me, b, p, front0, sf0, if0, rear0, sr0, ir0);
-            if (try_mobil) neighbour_update(sl, s_side, b, p, front1, sf1, if1, rear1, sr1, ir1);
-            if (lc_branch && same_road && b.present && b.lane != my_tl) {
+            neighbour_update(lf0, s_me, bp, bx, by, bk, p, n0);
+            if (try_mobil) neighbour_update(lf1, s_side, bp, bx, by, bk, p, n1);
+          }
+          if (__any(acting && lc_branch && same_road)) {  // the ongoing-lane-change abort test (:193-206) needs the partner as a Body
+            Body b = {bp, false, bx, by, 0.0, dppx_d<m>(v.v), 0.0, dppx_i<m>(v.lane), dppx_d<m>(spsi), dppx_d<m>(cpsi), bk};
+            if (acting && lc_branch && same_road && b.present && b.lane != my_tl) {
               const double sx = lane_sx(v.lane);
               const double d = (b.x - sx) - (v.x - sx);
               if (0 < d && d < desired_gap(self, b)) abort_mask |= 1u << p;
             }
           }
         });
+        if constexpr (MIXED) { STAMP(3); }  // HDV neighbour scan
         if (acting) {  // road.objects come after the vehicles (road.py:369)
-          Body ob = {true, true, kObstX, kObstY, 0.0, 0.0, 0.0, 0};
-          neighbour_update(v.lane, s_me, ob, 99, front0, sf0, if0, rear0, sr0, ir0);
-          if (try_mobil) neighbour_update(sl, s_side, ob, 99, front1, sf1, if1, rear1, sr1, ir1);
+          neighbour_update(lf0, s_me, true, kObstX, kObstY, koff_obst, 99, n0);
+          if (try_mobil) neighbour_update(lf1, s_side, true, kObstX, kObstY, koff_obst, 99, n1);
         }
+        // gather what IDM reads of the chosen bodies from their owners (all lanes: the shuffles sit in uniform control flow)
+        auto fetch = [&](int idx, bool full) {
+          Body r = {};
+          const int src = gb + ((idx >= 0 && idx < G) ? idx : 0);
+          r.x = shfl_d(v.x, src); r.v = shfl_d(v.v, src); r.sh = shfl_d(spsi, src); r.ch = shfl_d(cpsi, src);
+          if (full) { r.tspeed = shfl_d(v.tspeed, src); r.lane = shfl_i(v.lane, src); }
+          r.present = idx >= 0;
+          if (idx == 99) { r.is_object = true; r.x = kObstX; r.v = 0.0; r.sh = 0.0; r.ch = 1.0; r.tspeed = 0.0; r.lane = 0; }  // heading 0: sin 0, cos 1
+          return r;
+        };
+        const Body front0 = fetch(acting ? n0.i_front : -1, false);
+        Body front1 = {}, rear1 = {};
+        if (__any(try_mobil)) { front1 = fetch(try_mobil ? n1.i_front : -1, false); rear1 = fetch(try_mobil ? n1.i_rear : -1, true); }
+        const double acc_f0 = acting ? idm_acceleration(self, front0) : 0.0;  // (MOBIL's current-lane term and the HDV's own action)
         bool mobil_go = false;
         if (try_mobil) {  // mobil() behavior.py:225-266 (no route, POLITENESS = 0)
           const double nf_pred = idm_acceleration(rear1, self);
           if (!(nf_pred < -9.0)) {
-            const double jerk = idm_acceleration(self, front1) - idm_acceleration(self, front0) + 0.0;
+            const double jerk = idm_acceleration(self, front1) - acc_f0 + 0.0;
             mobil_go = !(jerk < 0.1);
           }
         }
+        if constexpr (MIXED) { STAMP(4); }  // gather + IDM / MOBIL
         if (acting && timer_due) v.gvx = 0;  // self.timer = 0 (:212)
         // fixed point on the post-act target lanes
         int tl_post = acting ? (lc_branch ? my_tl : (mobil_go ? side : my_tl)) : v.tlane;
@@ -1064,12 +1103,15 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
           tl_post = nxt;
           if (!__any(changed)) break;
         }
+        if constexpr (MIXED) { STAMP(5); }  // target-lane fixed point
         if (acting) {
           v.tlane = tl_post;
-          v.act_steer = clipd(steering_control(v.x, v.y, v.h, v.v, v.tlane, st_t), -kPi / 3, kPi / 3);
-          v.act_acc = clipd(idm_acceleration(self, front0), -6.0, 6.0);
+          v.act_acc = clipd(acc_f0, -6.0, 6.0);
         }
       }
+      // one steering_control for every vehicle that steers this sub-step: the CAVs, and the HDVs that acted (a crashed HDV
+      // keeps its last action)
+      if (live && (!hdv || !v.crashed)) steer_lane(v, sv && !hdv, st_t);
       if (hdv && live) v.gvx += dt;  // IDMVehicle.step: self.timer += dt (behavior.py:102-109)
     }
     if (live) clip_actions(v, LC && !hdv, st_t);
@@ -1384,19 +1426,31 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
         double wgu = slot_gu<MASS>(whvx, MASS ? wacc : kCbfAccLo, wg, dt);
         bool w_stepped = false;  // my published view is already the post-step one
         double twin_shift = 0;   // in-place edits egos made to my history record this sub-step
-        for (int r = 0; r < st.N; r++) {
-          if (MIXED && live && hdv && rank == r && !w_stepped) {
-            // an HDV at its turn just steps (no shield): later egos see its post-step pose, and its
-            // state_hist[-2] is then the record it held as [-1] before
-            const Cand ca = chosen(false);
-            wx = ca.x; wy = ca.y; wh = ca.h; wpk = ca.pk;
-            whx = s_cold[C_H1X][tid]; whvx = s_cold[C_H1VX][tid]; w_stepped = true; twin_shift = 0;
-            wgu = slot_gu<MASS>(whvx, MASS ? wacc : kCbfAccLo, wg, dt);
-          }
-          const unsigned sel = group_ballot<G>(shield_on && rank == r, gb);
+        // One stage per SHIELDED vehicle of the group, in sweep order -- not one per rank: a rank held by an HDV (or by no
+        // vehicle) has no shield to run, and with 4 CAVs + 4 HDVs that was half of the stages.  srank = my position among
+        // the group's shielded vehicles; the wave leaves when no group has a j-th one.
+        int srank = 0;
+        for_partners<G>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          srank += (dppx_i<m>(shield_on ? rank : 99) < rank) ? 1 : 0;
+        });
+        for (int j = 0; j < st.N; j++) {
+          const unsigned sel = group_ballot<G>(shield_on && srank == j, gb);
+          if (!__any(sel != 0)) break;
           const bool has = sel != 0;
           const int ai = has ? (__ffs((int)sel) - 1) : 0;
           const int src = gb + ai;
+          if constexpr (MIXED) {
+            // an HDV that comes before this ego in the sweep has stepped by now (no shield): the ego sees its post-step
+            // pose, and its state_hist[-2] is then the record it held as [-1] before
+            const int r_ego = shfl_i(rank, src);
+            if (live && hdv && has && rank < r_ego && !w_stepped) {
+              const Cand ca = chosen(false);
+              wx = ca.x; wy = ca.y; wh = ca.h; wpk = ca.pk;
+              whx = s_cold[C_H1X][tid]; whvx = s_cold[C_H1VX][tid]; w_stepped = true; twin_shift = 0;
+              wgu = slot_gu<MASS>(whvx, MASS ? wacc : kCbfAccLo, wg, dt);
+            }
+          }
           const double ex = shfl_d(v.x, src), ey = shfl_d(v.y, src);
           const int epk = shfl_i(pk_self, src);
           const double e_vx = shfl_d(v.v * cpsi, src);  // vehicle.velocity[0] of the ego

@@ -6,9 +6,10 @@ os.environ["MM_HIP_LIB"] = os.path.join(REPO, "marl-mass_amd", "csrc", "libmm_hi
 import torch
 from marl_mass_amd import VecMergeEnv, hip_library
 shield = sys.argv[1] if len(sys.argv) > 1 else "cbf-cav"
+n_hdv = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # mixed traffic: build the stamps library with -DMM_ONLY_MIXED=true
 E, N = 65536, 8
 metrics_on = not os.environ.get("MM_BENCH_NO_METRICS")
-env = VecMergeEnv(E, N, config={"safety_guarantee": shield, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5, seed=1000, auto_reset=True)
+env = VecMergeEnv(E, N, config={"safety_guarantee": shield, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5, seed=1000, auto_reset=True, n_hdv=n_hdv)
 if metrics_on: env.enable_metrics()
 env.reset()
 from marl_mass_amd import _cabi as abi
@@ -37,5 +38,5 @@ out = {"workload": "65536 envs x 8 CAVs, %s, stationary batch (staggered phases 
        "share": {n: buf[k] / tot for k, n in enumerate(names) if k != 13},
        "shielded_wave_substeps": int(buf[13])}
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(REPO, "gpurun_out", "phase_cycles_%s.json" % shield), "w"), indent=1)
+json.dump(out, open(os.path.join(REPO, "gpurun_out", "phase_cycles_%s%s.json" % (shield, "_hdv%d" % n_hdv if n_hdv else "")), "w"), indent=1)
 print("shielded wave-sub-steps %d" % buf[13])
