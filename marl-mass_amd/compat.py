@@ -422,9 +422,13 @@ def safety_layer(safety_type, action, vehicle, dt, safe_dist="theadway", **kwarg
     """decentral_layer.py:767-817: (safe_action, safe_diff, status) for one vehicle of a MergeEnvCompat.
 
     `vehicle` is one of `env.controlled_vehicles`; `action` its nominal {"steering", "acceleration"}.
-    The evaluation runs on the device (`mm_shield_actions`) against the env's current state; unlike the
-    reference it has no side effects on the vehicle -- is_lc_safe / is_collaborating / collaborate_adj
-    are returned in `status` next to is_optimal / is_safe / is_invariant."""
+    The evaluation runs on the device (`mm_shield_actions`) against the env's current state.  The reference call
+    also WRITES to the vehicle (decentral_layer.py:497-506 / :725-752): `is_collaborating`, `is_lc_safe`,
+    `collaborate_adj` (MASS) and, when the lane change is vetoed, `target_lane_index = lane_index`; this shim does
+    the same on the vehicle's state planes (so the next `env.step` sees them exactly as after the reference call)
+    and also returns the three flags in `status` next to is_optimal / is_safe / is_invariant.  What it does not
+    reproduce: `vehicle.min_headway` (a logging attribute) and the in-place history edit of an HDV twin, which the
+    in-step shield applies itself."""
     if safety_type not in ("hss", "av", "avs", "avs_cint", "mass", "cav"):
         raise ValueError("Undefined safety_type:{0}".format(safety_type))
     if safe_dist != "theadway":
@@ -450,4 +454,13 @@ def safety_layer(safety_type, action, vehicle, dt, safe_dist="theadway", **kwarg
     status = {"is_optimal": float(bool(bits & abi.ST_IS_OPTIMAL)), "is_safe": float(bool(bits & abi.ST_IS_SAFE)),
               "is_invariant": float(bool(bits & abi.ST_IS_INVARIANT)), "is_lc_safe": bool(bits & abi.ST_IS_LC_SAFE),
               "is_collaborating": bool(bits & abi.ST_IS_COLLABORATING), "collaborate_adj": bool(bits & abi.ST_COLLABORATE_ADJ)}
+    # the call's side effects on the vehicle (see the docstring)
+    flags = (abi.FLAG_IS_LC_SAFE if status["is_lc_safe"] else 0) | (abi.FLAG_IS_COLLABORATING if status["is_collaborating"] else 0)
+    if want == abi.SHIELD_MASS:
+        flags |= abi.FLAG_COLLABORATE_ADJ if status["collaborate_adj"] else 0
+    else:  # HSS leaves vehicle.collaborate_adj as it was
+        flags |= int(b.u8[abi.B["FLAGS"], 0, vehicle.id]) & abi.FLAG_COLLABORATE_ADJ
+    b.u8[abi.B["FLAGS"], 0, vehicle.id] = flags
+    if not status["is_lc_safe"]:  # "Avoiding lane change"
+        b.u8[abi.B["TARGET_LANE"], 0, vehicle.id] = b.u8[abi.B["LANE"], 0, vehicle.id]
     return safe_action, safe_diff, status

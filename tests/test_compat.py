@@ -233,6 +233,13 @@ def test_safety_layer_shim():
     assert set(sa) == {"acceleration", "steering"} and set(st) >= {"is_optimal", "is_safe", "is_invariant"}
     assert abs(sd["acceleration"] - (sa["acceleration"] - act["acceleration"])) < 1e-15
     assert sa["acceleration"] <= 6.0 + 1e-9  # within the acceleration bound of the QP
+    # the call's side effects on the vehicle (decentral_layer.py:725-752): the three flags, and the target lane on a veto --
+    # what the reference's own probes recorded as vehicle attributes after the call (tests/golden/sl_*: status columns 3-5)
+    for v in env.controlled_vehicles:
+        sa_v, _, st_v = compat.safety_layer("cav", {"steering": 0.2, "acceleration": 1.0}, v, 1 / 15)
+        assert (v.is_lc_safe, v.is_collaborating, v.collaborate_adj) == (st_v["is_lc_safe"], st_v["is_collaborating"], st_v["collaborate_adj"])
+        if not st_v["is_lc_safe"]:
+            assert v.target_lane_index == v.lane_index
     with pytest.raises(ValueError):
         compat.safety_layer("avs_cint", act, veh, 1 / 15)  # env is configured for MASS
     with pytest.raises(ValueError):
