@@ -2142,6 +2142,18 @@ static int check_cfg(const MMConfig *c, int N, char *err) {
 }
 
 static thread_local char g_create_err[256] = "null handle";  // why the last mm_create of this thread refused (there is no handle to ask)
+// The host-side entries that touch the runtime outside a stream (allocation, latch poll, drain) must address the handle's
+// device, but the caller's current device is the caller's: it is put back on exit (a two-GPU process polling the env of the
+// other GPU would otherwise find torch's current device changed under it).
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t rc;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    rc = hipSetDevice(device);
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 static int hip_fail(MMHandle h, hipError_t e, const char *what) {
   snprintf(h->err, sizeof h->err, "%s: %s", what, hipGetErrorString(e));
   return MM_ERR_DEVICE;
@@ -2164,7 +2176,8 @@ extern "C" int32_t mm_create(const MMConfig *cfg, int32_t E, int32_t N, int32_t 
   // per-env seed plane: cfg.seed + global env index
   uint64_t *tmp = (uint64_t *)malloc((size_t)E * 8u);
   for (int64_t e = 0; e < E; e++) tmp[e] = cfg->seed + (uint64_t)(first_env + e);
-  hipError_t rc = hipSetDevice(device);
+  DeviceGuard dg(device);
+  hipError_t rc = dg.rc;
   if (rc == hipSuccess) rc = hipMemcpy(h->state + h->lay.seed_offset, tmp, (size_t)E * 8u, hipMemcpyHostToDevice);
   free(tmp);
   if (rc == hipSuccess) rc = hipMalloc((void **)&h->dev_err, MM_LW_COUNT * sizeof(int));
@@ -2176,7 +2189,8 @@ extern "C" int32_t mm_create(const MMConfig *cfg, int32_t E, int32_t N, int32_t 
 extern "C" int32_t mm_destroy(MMHandle h) {
   if (!h) return MM_OK;
   // launches of this handle may still be in flight and they write its error latch: drain the device first
-  hipError_t rc = hipSetDevice(h->device);
+  DeviceGuard dg(h->device);
+  hipError_t rc = dg.rc;
   if (rc == hipSuccess) rc = hipDeviceSynchronize();
   if (h->dev_err) (void)hipFree(h->dev_err);
   if (h->metrics_partial) (void)hipFree(h->metrics_partial);
@@ -2186,7 +2200,8 @@ extern "C" int32_t mm_destroy(MMHandle h) {
 // include/mm_abi.h: conditions the reference raises inside step(), latched by the kernels
 static int poll_latch(MMHandle h, int word, MMStream stream) {
   int bits = 0;
-  hipError_t rc = hipSetDevice(h->device);  // (a multi-GPU process may have another device current)
+  DeviceGuard dg(h->device);  // (a multi-GPU process may have another device current)
+  hipError_t rc = dg.rc;
   if (rc == hipSuccess) rc = hipStreamSynchronize((hipStream_t)stream);
   if (rc == hipSuccess) rc = hipMemcpy(&bits, h->dev_err + word, sizeof bits, hipMemcpyDeviceToHost);
   if (rc == hipSuccess && bits) rc = hipMemset(h->dev_err + word, 0, sizeof(int));
@@ -2216,7 +2231,8 @@ extern "C" int32_t mm_set_metrics_buffer(MMHandle h, double *metrics) {
   if (!h) return MM_ERR_INVALID_ARG;
   if (metrics && !h->metrics_partial) {  // per-wave partials of one step launch (allocated here, never inside step)
     const long long waves = step_launch_waves(h);
-    hipError_t rc = hipSetDevice(h->device);
+    DeviceGuard dg(h->device);
+    hipError_t rc = dg.rc;
     if (rc == hipSuccess) rc = hipMalloc((void **)&h->metrics_partial, (size_t)waves * 8 * sizeof(double));
     if (rc != hipSuccess) return hip_fail(h, rc, "metrics partial buffer");
   }

@@ -222,6 +222,9 @@ class DeviceRollout(object):
         merge_percents -- per env as tensors."""
         env = self.env
         E, N, dev = env.E, env.N, self.obs.device
+        missing = [k for k in ("agents_info", "crashed") if k not in env.out]
+        if missing:  # MAPPO.evaluation reads info["vehicle_speed"/"vehicle_position"] and env.is_crashed() (:300-330)
+            raise ValueError("evaluate() needs the step outputs %s: this env was built with skip_outputs" % ", ".join(missing))
         was_auto = env.auto_reset
         # The reference evaluates on a SEPARATE env (env_eval, run_mappo.py:146-171,300-306) and its training env keeps
         # its own seed sequence and in-progress episode.  Here the batch is borrowed: snapshot everything an evaluation

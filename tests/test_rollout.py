@@ -330,3 +330,15 @@ def test_graph_rollout_survives_evaluate_and_reseed():
     torch.cuda.synchronize()
     for k in ("states", "actions", "returns", "dones"):
         assert torch.equal(a[k], b[k]), ("after reseed", k)
+
+
+def test_evaluate_refuses_an_env_without_the_outputs_it_reads():
+    """MAPPO.evaluation reads the vehicles' speed / position and the crash flag of every step (marl/mappo.py:300-330): a
+    batch built with those outputs skipped cannot be evaluated, and says so before it touches the batch."""
+    env = oracle_env.OracleEnv(2, 4, env_id="merge-multi-agent-v1", config={"safety_guarantee": "none"}, seed=3,
+                               auto_reset=True, skip_outputs=("agents_info",))
+    ro = DeviceRollout(env, ActorNetwork(30, 128, 5), CriticNetwork(30, 5, 128), roll_out_n_steps=5, sample_seed=1)
+    before = env.state.clone()
+    with pytest.raises(ValueError, match="agents_info"):
+        ro.evaluate(seeds=[1, 2])
+    assert torch.equal(env.state, before) and env.auto_reset
