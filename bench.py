@@ -249,7 +249,9 @@ def main():
         if os.environ.get("MM_BENCH_NO_METRICS"):  # tuning experiment: no in-kernel metric accumulation
             metrics = torch.zeros(8, dtype=torch.float64, device=dev)
         else:
-            metrics = env.enable_metrics()
+            # a rollout loop reads its metrics once, at the end (marl/mappo.py:348-354): the per-wave partials are folded into the
+            # 8 doubles by ONE launch at the end of the timed region, not by one small launch behind every step
+            metrics = env.enable_metrics(deferred=True)
         env.reset()
         g = torch.Generator(device=dev).manual_seed(123 + rank)
         p = torch.tensor([0.1, 0.6, 0.1, 0.1, 0.1], device=dev)
@@ -264,6 +266,7 @@ def main():
                 env.step(ring[t % 16])
         for t in range(warmup):
             env.step(ring[t % 16])
+        env.flush_metrics()  # (what pre-roll and warm-up accumulated is not part of the measurement)
         torch.cuda.synchronize()
         metrics.zero_()
         metrics[7] = float("inf")
@@ -282,6 +285,7 @@ def main():
                 ev[t][1].record()
             else:
                 env.step(ring[t % 16])
+        env.flush_metrics()  # end of the rollout: fold the per-wave partials (inside the timed region)
         torch.cuda.synchronize()
         barrier()
         elapsed = time.perf_counter() - t0
@@ -375,9 +379,9 @@ def main():
                                          "committed under profiles/ (see profiles/traffic.json: source)",
                          "alg_bytes_per_launch": E * N * b_alg,
                          "kernel": "step_kernel", "kernel_ms": kern_ms, "alg_bytes_per_agent_step": b_alg,
-                         "kernel_ms_note": "HIP events around every 8th mm_step of the timed region on its launch stream = step_kernel + the "
-                                           "32-block metrics_flush_kernel behind it (~4 us); rocprofv3's step_kernel average (profiles/) is "
-                                           "that much lower"},
+                         "kernel_ms_note": "HIP events around every 8th mm_step of the timed region on its launch stream = step_kernel alone "
+                                           "(the rollout metrics are deferred: one metrics_flush_kernel at the end of the timed region) + "
+                                           "the events' own gaps; rocprofv3's step_kernel average is under profiles/"},
             "rollout_metrics": {"mean_reward": m[0] / max(m[4], 1), "crashed_episodes": m[1],
                                 "mean_speed": m[2] / max(m[4], 1), "env_steps": m[4],
                                 "mean_merge_percent": m[5] / max(m[6], 1), "episodes": m[6], "min_headway": m[7]},

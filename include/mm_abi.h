@@ -315,6 +315,18 @@ int32_t mm_poll_errors(MMHandle h, MMStream stream);
  */
 int32_t mm_set_metrics_buffer(MMHandle h, double *metrics);
 
+/*
+ * Deferred folding of the rollout metrics.  By default every mm_step is followed by a small launch that folds the
+ * step's per-wave partial sums into the caller's 8 doubles, so they are current after every step.  A rollout loop
+ * (marl/mappo.py:102-158) reads them once, at its end: with deferred != 0 the partials accumulate across steps in the
+ * handle's own device buffer and reach the caller's 8 doubles only in mm_flush_metrics -- which mm_poll_errors also
+ * calls -- i.e. one fold per rollout instead of one per step (the fold is 4 of the 75 microseconds of a step at 8 192
+ * envs).  Needs a metrics buffer (mm_set_metrics_buffer first); turning deferral off flushes.  Both calls only
+ * enqueue work on `stream` (the stream of the mm_step calls).
+ */
+int32_t mm_defer_metrics(MMHandle h, int32_t deferred, MMStream stream);
+int32_t mm_flush_metrics(MMHandle h, MMStream stream);
+
 const char *mm_last_error(MMHandle h);
 
 /*

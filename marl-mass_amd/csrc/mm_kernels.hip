@@ -43,6 +43,7 @@ struct DevCfg {
   int traffic_density, mixed_traffic, num_cav;  // per-episode vehicle-count draw (MergeEnv._num_vehicles); 0 = fixed counts
 };
 // conditions the reference raises from inside step(); a launch can only latch them (include/mm_abi.h: mm_poll_errors)
+constexpr int kMetricsAccBit = 30;  // internal bit of DevCfg::debug_flags (set by dev_cfg, never by the caller): metrics partials accumulate
 #define MM_LATCH_QP_BOUNDS 1  // CBFType.check_bounds, cbf.py:87-96
 #define MM_LATCH_BAD_ACTION 2 // DiscreteMetaAction.act: self.actions[action] KeyError, action.py:194-196
 #define MM_LATCH_BAD_QP 4     // mm_shield_qp: G is not of the form get_G builds
@@ -1797,7 +1798,13 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
         const double x = s_cold[slot][base + j * G];
         acc = ln == 7 ? fmin(acc, x) : acc + x;
       }
-      metrics[(gtid >> 6) * 8 + ln] = acc;
+      double *row = metrics + (gtid >> 6) * 8;  // this wave's row of the partial buffer
+      if ((c.debug_flags >> kMetricsAccBit) & 1) {  // deferred folding (mm_defer_metrics): the row accumulates across launches; fire and forget
+        if (ln == 7) (void)unsafeAtomicMin(&row[7], acc);
+        else (void)unsafeAtomicAdd(&row[ln], acc);
+      } else {
+        row[ln] = acc;
+      }
     }
   }
   STAMP(15);  // metrics
@@ -2058,7 +2065,8 @@ __global__ void qp_kernel(int n, const double *__restrict__ G, const double *__r
 // 256 waves' partials (8 independent loads per thread in flight), reduces them in LDS and issues 8 atomics
 #if MM_TU <= 1
 constexpr int kFlushWaves = 256;
-__global__ __launch_bounds__(256) void metrics_flush_kernel(const double *__restrict__ partial, long long waves, double *metrics) {
+// reset: the partials were accumulated over several launches (mm_defer_metrics) -- put every row back to the identity
+__global__ __launch_bounds__(256) void metrics_flush_kernel(double *partial, long long waves, double *metrics, int reset) {
   __shared__ double s_p[32][8];
   const int k = threadIdx.x & 7, r = threadIdx.x >> 3;
   const long long w0 = (long long)blockIdx.x * kFlushWaves;
@@ -2067,10 +2075,12 @@ __global__ __launch_bounds__(256) void metrics_flush_kernel(const double *__rest
   for (int j = 0; j < kFlushWaves / 32; j++) {
     const long long w = w0 + r + 32 * j;
     x[j] = w < waves ? partial[w * 8 + k] : (k == 7 ? INFINITY : 0.0);
+    if (reset && w < waves) partial[w * 8 + k] = k == 7 ? INFINITY : 0.0;
   }
   double acc = k == 7 ? INFINITY : 0.0;
 #pragma unroll
   for (int j = 0; j < kFlushWaves / 32; j++) acc = k == 7 ? fmin(acc, x[j]) : acc + x[j];
+  if (reset == 2) return;  // (mm_defer_metrics: rows to the identity, nothing folded -- block-uniform)
   s_p[r][k] = acc;
   __syncthreads();
   if (threadIdx.x < 8) {
@@ -2095,6 +2105,7 @@ struct MMHandle_ {
   long long first_env;
   double *metrics;          // caller's 8 doubles (mm_set_metrics_buffer) or NULL
   double *metrics_partial;  // [waves of a step launch][8], device, owned by the handle
+  int metrics_deferred;     // mm_defer_metrics: the partials accumulate across launches, folded by mm_flush_metrics only
   // device error latches (MM_LATCH_* bits), hipMalloc'd at create.  One word per entry point that reports synchronously, so
   // that a condition latched by an un-polled mm_step cannot fail a later, valid mm_shield_qp / mm_shield_actions call (or be
   // consumed by it): [MM_LW_STEP] mm_step -> mm_poll_errors, [MM_LW_QP] mm_shield_qp, [MM_LW_SHIELD] mm_shield_actions
@@ -2217,8 +2228,41 @@ static int poll_latch(MMHandle h, int word, MMStream stream) {
   if (bits & MM_LATCH_QP_BOUNDS) return MM_ERR_QP_BOUNDS;
   return MM_ERR_INVALID_ARG;
 }
+static void launch_metrics_flush(MMHandle h, hipStream_t s, int reset) {
+  const long long waves = step_launch_waves(h);
+  hipLaunchKernelGGL(metrics_flush_kernel, dim3((unsigned)((waves + kFlushWaves - 1) / kFlushWaves)), dim3(256), 0, s,
+                     h->metrics_partial, waves, h->metrics, reset);
+}
+extern "C" int32_t mm_flush_metrics(MMHandle h, MMStream stream) {
+  if (!h) return MM_ERR_INVALID_ARG;
+  if (!h->metrics_deferred || !h->metrics) return MM_OK;  // (not deferred: the caller's buffer is current after every step)
+  launch_metrics_flush(h, (hipStream_t)stream, 1);
+  const hipError_t rc = hipGetLastError();
+  return rc == hipSuccess ? MM_OK : hip_fail(h, rc, "metrics flush");
+}
+extern "C" int32_t mm_defer_metrics(MMHandle h, int32_t deferred, MMStream stream) {
+  if (!h) return MM_ERR_INVALID_ARG;
+  if (deferred && !h->metrics) {
+    snprintf(h->err, sizeof h->err, "mm_defer_metrics: no metrics buffer (mm_set_metrics_buffer first)");
+    return MM_ERR_INVALID_ARG;
+  }
+  if ((deferred != 0) == (h->metrics_deferred != 0)) return MM_OK;
+  if (deferred) {  // every row to the identity (reset = 2: nothing is folded), then the step launches accumulate
+    const long long waves = step_launch_waves(h);
+    hipLaunchKernelGGL(metrics_flush_kernel, dim3((unsigned)((waves + kFlushWaves - 1) / kFlushWaves)), dim3(256), 0,
+                       (hipStream_t)stream, h->metrics_partial, waves, (double *)nullptr, 2);
+    h->metrics_deferred = 1;
+  } else {
+    launch_metrics_flush(h, (hipStream_t)stream, 1);
+    h->metrics_deferred = 0;
+  }
+  const hipError_t rc = hipGetLastError();
+  return rc == hipSuccess ? MM_OK : hip_fail(h, rc, "mm_defer_metrics");
+}
 extern "C" int32_t mm_poll_errors(MMHandle h, MMStream stream) {
   if (!h) return MM_ERR_INVALID_ARG;
+  const int frc = mm_flush_metrics(h, stream);  // deferred metrics: a poll is where a rollout loop synchronises anyway
+  if (frc != MM_OK) return frc;
   return poll_latch(h, MM_LW_STEP, stream);
 }
 extern "C" int32_t mm_set_config(MMHandle h, const MMConfig *cfg) {
@@ -2237,6 +2281,7 @@ extern "C" int32_t mm_set_metrics_buffer(MMHandle h, double *metrics) {
     if (rc != hipSuccess) return hip_fail(h, rc, "metrics partial buffer");
   }
   h->metrics = metrics;
+  if (!metrics) h->metrics_deferred = 0;  // (no buffer, nothing to defer; what the partials held is dropped)
   return MM_OK;
 }
 extern "C" const char *mm_last_error(MMHandle h) { return h ? h->err : g_create_err; }
@@ -2248,7 +2293,7 @@ static DevCfg dev_cfg(const MMHandle h) {
   d.env_kind = c.env_kind; d.shield = c.env_kind == MM_ENV_V1 ? c.shield : MM_SHIELD_NONE;
   d.nsub = c.simulation_frequency / c.policy_frequency; d.T = c.duration * c.policy_frequency;
   d.action_masking = c.action_masking; d.auto_reset = c.auto_reset; d.obs_f64 = c.obs_f64; d.N = h->N; d.E = h->E;
-  d.debug_flags = c.debug_flags; d.n_hdv = c.n_hdv;
+  d.debug_flags = (c.debug_flags & ~(1 << kMetricsAccBit)) | (h->metrics_deferred ? (1 << kMetricsAccBit) : 0); d.n_hdv = c.n_hdv;
   d.dt = 1.0 / c.simulation_frequency;
   d.collision_reward = c.collision_reward; d.high_speed_reward = c.high_speed_reward;
   d.headway_cost = c.headway_cost; d.headway_time = c.headway_time; d.merging_lane_cost = c.merging_lane_cost;
@@ -2425,11 +2470,7 @@ extern "C" int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *
     default: launch_step_g<16>(h, actions, out, s); break;
   }
 #endif
-  if (h->metrics) {  // fold this launch's per-wave partials into the caller's 8 doubles (same stream: ordered)
-    const long long waves = step_launch_waves(h);
-    hipLaunchKernelGGL(metrics_flush_kernel, dim3((unsigned)((waves + kFlushWaves - 1) / kFlushWaves)), dim3(256), 0, s,
-                       h->metrics_partial, waves, h->metrics);
-  }
+  if (h->metrics && !h->metrics_deferred) launch_metrics_flush(h, s, 0);  // fold this launch's per-wave partials into the caller's 8 doubles (same stream: ordered)
   hipError_t rc = hipGetLastError();
   return rc == hipSuccess ? MM_OK : hip_fail(h, rc, "step launch");
 }

@@ -193,7 +193,7 @@ class BatchedMergeEnv(object):
         d = {"abi_version": abi.MM_ABI_VERSION, "E": self.E, "N": self.N, "env_id": self.env_id,
              "state": self.state.clone(), "obs": self.obs.clone(), "avail": self.avail.clone()}
         if self.metrics is not None:
-            d["metrics"] = self.metrics.clone()
+            d["metrics"] = self.flush_metrics().clone()  # (deferred metrics: what the partials hold belongs to the snapshot)
         return d
 
     def load_state_dict(self, d):
@@ -203,13 +203,24 @@ class BatchedMergeEnv(object):
         self.obs.copy_(d["obs"].to(self.device))
         self.avail.copy_(d["avail"].to(self.device))
         if "metrics" in d and self.metrics is not None:
+            self.flush_metrics()  # (pending deferred sums belong to the state that is being replaced)
             self.metrics.copy_(d["metrics"].to(self.device))
 
-    def enable_metrics(self):
-        """Device-side rollout metric accumulator: 7 sums + 1 min."""
+    def enable_metrics(self, deferred=False):
+        """Device-side rollout metric accumulator: 7 sums + 1 min.
+        deferred: the per-step sums stay in the library's per-wave partials and reach the returned tensor only in
+        flush_metrics() / poll_errors() (mm_defer_metrics: one fold per rollout instead of one small launch per step)."""
         self.metrics = torch.zeros(8, dtype=torch.float64, device=self.device)
         self.metrics[7] = float("inf")
         self.clib.check(self.clib.lib.mm_set_metrics_buffer(self._h, _ptr(self.metrics)), self._h)
+        self.clib.check(self.clib.lib.mm_defer_metrics(self._h, 1 if deferred else 0, self._stream()), self._h)
+        self._metrics_deferred = bool(deferred)
+        return self.metrics
+
+    def flush_metrics(self):
+        """Fold what deferred metrics hold into the tensor enable_metrics() returned (stream-ordered; no-op if not deferred)."""
+        if self.metrics is not None:
+            self.clib.check(self.clib.lib.mm_flush_metrics(self._h, self._stream()), self._h)
         return self.metrics
 
     def poll_errors(self):

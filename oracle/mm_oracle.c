@@ -1506,6 +1506,14 @@ int32_t mm_set_config(MMHandle h, const MMConfig *cfg) {
   return rc;
 }
 int32_t mm_set_metrics_buffer(MMHandle h, double *metrics) { h->metrics = metrics; return MM_OK; }
+/* (the CPU twin adds every step's sums to the caller's buffer directly: there is nothing to defer or to flush) */
+int32_t mm_defer_metrics(MMHandle h, int32_t deferred, MMStream stream) {
+  (void)stream;
+  if (!h) return MM_ERR_INVALID_ARG;
+  if (deferred && !h->metrics) { snprintf(h->err, sizeof h->err, "mm_defer_metrics: no metrics buffer (mm_set_metrics_buffer first)"); return MM_ERR_INVALID_ARG; }
+  return MM_OK;
+}
+int32_t mm_flush_metrics(MMHandle h, MMStream stream) { (void)stream; return h ? MM_OK : MM_ERR_INVALID_ARG; }
 const char *mm_last_error(MMHandle h) { return h ? h->err : g_create_err; }
 
 int32_t mm_reset(MMHandle h, const uint8_t *env_mask, const uint64_t *seeds_in, void *obs,

@@ -140,3 +140,21 @@ def test_skipped_outputs_are_not_written_and_change_nothing_else():
         oracle_env.OracleEnv(4, 4, skip_outputs=("reward",), **kw)
     with pytest.raises(ValueError):  # with masking on, the mask is a result of the step
         oracle_env.OracleEnv(4, 4, env_id="merge-multi-agent-v0", config={"action_masking": True}, skip_outputs=("action_mask",))
+
+
+def test_deferred_metrics_calls_on_the_cpu_twin():
+    """mm_defer_metrics / mm_flush_metrics (mm_abi.h) exist on both libraries; the CPU twin adds every step's sums to the
+    caller's buffer directly, so deferral changes nothing there -- and without a metrics buffer the call is refused."""
+    import torch
+    import oracle_env
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "none"}, seed=3, auto_reset=True)
+    a, b = oracle_env.OracleEnv(16, 4, **kw), oracle_env.OracleEnv(16, 4, **kw)
+    ma, mb = a.enable_metrics(), b.enable_metrics(deferred=True)
+    a.reset(); b.reset()
+    act = torch.full((16, 4), 3, dtype=torch.int32)
+    for _ in range(8):
+        a.step(act); b.step(act)
+    assert torch.allclose(ma, b.flush_metrics(), rtol=1e-12, atol=0) and float(mb[4]) == 8 * 16  # (OpenMP sums: order varies)
+    c = oracle_env.OracleEnv(4, 4, **kw)
+    assert c.clib.lib.mm_defer_metrics(c._h, 1, None) == abi.MM_ERR_INVALID_ARG
+    assert c.clib.lib.mm_defer_metrics(c._h, 0, None) == abi.MM_OK and c.clib.lib.mm_flush_metrics(c._h, None) == abi.MM_OK

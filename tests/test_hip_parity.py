@@ -331,6 +331,39 @@ def test_metrics_accumulator():
     assert float(mm[7]) == mn
 
 
+def test_deferred_metrics_match_per_step_folding():
+    """mm_defer_metrics: the per-wave partials accumulate across steps and reach the caller's 8 doubles only in
+    mm_flush_metrics / mm_poll_errors -- same totals as the per-step fold (sums up to reassociation, min and counts exactly),
+    nothing visible before the flush, nothing counted twice by a second flush, and switching deferral off flushes."""
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125,
+              cbf_tau=0.5, seed=5, auto_reset=True)
+    a_env, b_env = _gpu_env(777, 8, **kw), _gpu_env(777, 8, **kw)   # (777 envs: the last wave of a launch is partly empty)
+    ma, mb = a_env.enable_metrics(), b_env.enable_metrics(deferred=True)
+    a_env.reset(); b_env.reset()
+    g = torch.Generator().manual_seed(9)
+    p = torch.tensor([0.2, 0.3, 0.2, 0.2, 0.1])
+    for t in range(120):   # (episodes end and re-spawn inside the window: crashed / merge % / episode counters move)
+        act = torch.multinomial(p, 777 * 8, True, generator=g).view(777, 8).int().cuda()
+        a_env.step(act); b_env.step(act)
+        if t == 50:
+            torch.cuda.synchronize()
+            assert float(mb[4]) == 0.0 and float(mb[7]) == float("inf"), "deferred sums became visible before a flush"
+            b_env.flush_metrics(); b_env.flush_metrics()   # (the second flush has nothing left to add)
+            torch.cuda.synchronize()
+            assert float(mb[4]) == float(ma[4]) == 51 * 777
+    b_env.poll_errors()   # flushes, then synchronises
+    assert torch.equal(ma[[1, 4, 6, 7]], mb[[1, 4, 6, 7]]) and float(ma[6]) > 0
+    assert torch.allclose(ma, mb, rtol=1e-12, atol=0)
+    # a snapshot taken in deferred mode contains the pending sums; turning deferral off flushes and goes back to per-step folds
+    b_env.step(act); a_env.step(act)
+    assert torch.allclose(b_env.state_dict()["metrics"], ma, rtol=1e-12, atol=0)
+    b_env.step(act); a_env.step(act)
+    b_env.clib.check(b_env.clib.lib.mm_defer_metrics(b_env._h, 0, b_env._stream()), b_env._h)
+    b_env.step(act); a_env.step(act)
+    torch.cuda.synchronize()
+    assert torch.allclose(ma, mb, rtol=1e-12, atol=0) and float(mb[4]) == 123 * 777
+
+
 def test_full_size_bit_exact_vs_oracle():
     """BASELINE's headline size (65536 envs x 8 CAVs, MASS, auto-reset) for 12 steps against the
     OpenMP oracle: every state bit, obs, reward, done of all 524 288 agents."""
