@@ -7,7 +7,7 @@ import torch
 from marl_mass_amd import VecMergeEnv, hip_library
 shield = sys.argv[1] if len(sys.argv) > 1 else "cbf-cav"
 n_hdv = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # mixed traffic: build the stamps library with -DMM_ONLY_MIXED=true
-E, N = 65536, 8
+E, N = int(os.environ.get("MM_STAMPS_E", "65536")), 8   # (MM_STAMPS_E=8192: one wave per SIMD, the latency-bound case)
 metrics_on = not os.environ.get("MM_BENCH_NO_METRICS")
 env = VecMergeEnv(E, N, config={"safety_guarantee": shield, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5, seed=1000, auto_reset=True, n_hdv=n_hdv)
 if metrics_on: env.enable_metrics()
@@ -32,11 +32,11 @@ for k, nme in enumerate(names):
     print("%-20s %6.2f %%   %8.0f cycles/wave/step" % (nme, 100.0 * buf[k] / tot, buf[k] / waves / K))
 print("total %.0f cycles/wave/step" % (tot / waves / K))
 import json
-out = {"workload": "65536 envs x 8 CAVs, %s, stationary batch (staggered phases + 100-step pre-roll), %d steps" % (shield, K),
+out = {"workload": "%d envs x 8 CAVs, %s, stationary batch (staggered phases + 100-step pre-roll), %d steps" % (E, shield, K),
        "build": "-DMM_STAMPS -DMM_ONLY_G=8 -DMM_ONLY_MIXED=false (s_memtime stamps cost ~10 %% themselves)",
        "cycles_per_wave_step": {n: buf[k] / waves / K for k, n in enumerate(names) if k != 13}, "total_cycles_per_wave_step": tot / waves / K,
        "share": {n: buf[k] / tot for k, n in enumerate(names) if k != 13},
        "shielded_wave_substeps": int(buf[13])}
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(REPO, "gpurun_out", "phase_cycles_%s%s.json" % (shield, "_hdv%d" % n_hdv if n_hdv else "")), "w"), indent=1)
+json.dump(out, open(os.path.join(REPO, "gpurun_out", "phase_cycles_%s%s%s.json" % (shield, "_hdv%d" % n_hdv if n_hdv else "", "" if E == 65536 else "_E%d" % E)), "w"), indent=1)
 print("shielded wave-sub-steps %d" % buf[13])
