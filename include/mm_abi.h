@@ -355,6 +355,21 @@ int32_t mm_policy_act(const float *obs, int64_t n, int32_t n_s, const float *W1,
                       uint64_t *counter, int32_t *actions, float *logp, MMStream stream);
 
 /*
+ * End of a rollout (marl/mappo.py:147-156 + _discount_reward :364-370), for every agent of a batch at once:
+ *   rewards = rewards / reward_scale            (reward_scale > 0; :152-153)
+ *   running = final_value;  for t = T-1 .. 0:  if done[t][e]: running = 0;  running = running * gamma + rewards[t];
+ *   returns[t] = running
+ * -- the reference discounts one episode list per agent; a `done` at step t cuts the chain, because what follows in
+ * the batch's rollout belongs to the next episode of that env slot.  One thread per agent walks its T values once
+ * (2 x 8 B per value of traffic) instead of three element-wise launches per step of the rollout.  fp64, one rounding
+ * per operation in the order written.  rewards: DEV double[T][n_env][n_agent]; dones: DEV uint8[T][n_env];
+ * final_value: DEV double[n_env][n_agent]; returns: DEV double[T][n_env][n_agent] (may alias rewards).  Stateless.
+ */
+int32_t mm_discount_returns(const double *rewards, const uint8_t *dones, const double *final_value, int32_t T,
+                            int64_t n_env, int32_t n_agent, double gamma, double reward_scale, double *returns,
+                            MMStream stream);
+
+/*
  * Diagnostics: evaluate one elementary function of include/mm_math.h element-wise
  * (fn: 0 sin, 1 cos, 2 tan, 3 atan, 4 asin, 5 exp, 6 log, 7 sqrt, 8 x/y with y = x2[i],
  * 9 x/y through the HIP path's constant-divisor form div_c (the oracle uses plain division)).

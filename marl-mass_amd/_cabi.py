@@ -182,7 +182,7 @@ class CLib(object):
     SYMBOLS = ["mm_abi_version", "mm_state_layout", "mm_create", "mm_destroy", "mm_set_config",
                "mm_reset", "mm_init_from_kinematics", "mm_observe", "mm_step", "mm_shield_qp",
                "mm_set_metrics_buffer", "mm_last_error", "mm_math_eval", "mm_shield_actions", "mm_sample_actions",
-               "mm_policy_act", "mm_poll_errors", "mm_geom_eval", "mm_defer_metrics", "mm_flush_metrics"]
+               "mm_policy_act", "mm_poll_errors", "mm_geom_eval", "mm_defer_metrics", "mm_flush_metrics", "mm_discount_returns"]
 
     def __init__(self, path):
         if not os.path.exists(path):
@@ -205,6 +205,7 @@ class CLib(object):
         lib.mm_set_metrics_buffer.argtypes = [vp, vp]
         lib.mm_defer_metrics.argtypes = [vp, i32, vp]
         lib.mm_flush_metrics.argtypes = [vp, vp]
+        lib.mm_discount_returns.argtypes = [vp, vp, vp, i32, i64, i32, C.c_double, C.c_double, vp, vp]
         lib.mm_last_error.argtypes = [vp]
         lib.mm_math_eval.argtypes = [i32, i32, vp, vp, vp, vp]
         lib.mm_geom_eval.argtypes = [i32, i32, vp, vp, vp]

@@ -2625,6 +2625,35 @@ extern "C" int32_t mm_sample_actions(const float *logp, int64_t n, int32_t n_a, 
   return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_DEVICE;
 }
 
+// marl/mappo.py:147-156,364-370: reward scaling + discounted returns of a whole rollout, one thread per agent, T values
+// each, consecutive threads on consecutive addresses at every t (include/mm_abi.h: mm_discount_returns)
+__global__ __launch_bounds__(256) void discount_kernel(const double *rewards, const uint8_t *__restrict__ dones,
+                                                       const double *__restrict__ final_value, int T, long long n_env, int n_agent,
+                                                       double gamma, double scale, double *returns) {
+  const long long A = n_env * n_agent;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A) return;
+  const long long e = i / n_agent;
+  double running = final_value[i];
+  for (int t = T - 1; t >= 0; t--) {
+    double r = rewards[(long long)t * A + i];
+    if (scale > 0) r = r / scale;
+    if (dones[(long long)t * n_env + e]) running = 0.0;
+    running = running * gamma + r;
+    returns[(long long)t * A + i] = running;
+  }
+}
+extern "C" int32_t mm_discount_returns(const double *rewards, const uint8_t *dones, const double *final_value, int32_t T,
+                                       int64_t n_env, int32_t n_agent, double gamma, double reward_scale, double *returns,
+                                       MMStream stream) {
+  if (!rewards || !dones || !final_value || !returns || T < 0 || n_env < 0 || n_agent < 1) return MM_ERR_INVALID_ARG;
+  const long long A = (long long)n_env * n_agent;
+  if (A == 0 || T == 0) return MM_OK;
+  hipLaunchKernelGGL(discount_kernel, dim3((unsigned)((A + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rewards, dones,
+                     final_value, (int)T, (long long)n_env, (int)n_agent, gamma, reward_scale, returns);
+  return hipGetLastError() == hipSuccess ? MM_OK : MM_ERR_DEVICE;
+}
+
 // ------------------------------------------------------------------------------------------------
 // mm_policy_act: the actor forward of the rollout loop fused with the sampling above
 // (marl/single_agent/Model_common.py:5-22 ActorNetwork: n_s -> 128 -> 128 -> n_a, ReLU, log-softmax;

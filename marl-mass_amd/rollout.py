@@ -112,13 +112,20 @@ class DeviceRollout(object):
             self._graph, self._static = None, None  # the seed is a kernel argument baked into the capture: re-capture
 
     @torch.no_grad()
-    def act(self, obs):
-        """exploration_action / action (marl/mappo.py:220-236): sample from softmax(actor(obs))."""
+    def act(self, obs, out=None):
+        """exploration_action / action (marl/mappo.py:220-236): sample from softmax(actor(obs)).
+        out: optional int32 [E, N] buffer (contiguous, on the device) the actions are written to -- a rollout's actions[t]."""
+        if out is not None:
+            assert out.shape == obs.shape[:2] and out.dtype == torch.int32 and out.device == obs.device and out.is_contiguous()
+            return self._act(obs, out.view(-1))
+        return self._act(obs, None)
+
+    def _act(self, obs, dst):
         E, N, S = obs.shape
         if self.generator is None and self.fused_policy and type(self.actor) is ActorNetwork and obs.dtype == torch.float32:
             # actor forward + sampling in ONE launch (mm_policy_act: f32 MFMA, activations in registers)
             a, clib = self.actor, self.env.clib
-            actions = torch.empty(E * N, dtype=torch.int32, device=obs.device)
+            actions = dst if dst is not None else torch.empty(E * N, dtype=torch.int32, device=obs.device)
             ptr = lambda t: t.detach().contiguous().data_ptr()  # noqa: E731  (nn.Linear parameters are contiguous)
             clib.check(clib.lib.mm_policy_act(obs.contiguous().data_ptr(), E * N, S, ptr(a.fc1.weight), ptr(a.fc1.bias),
                                               ptr(a.fc2.weight), ptr(a.fc2.bias), ptr(a.fc3.weight), ptr(a.fc3.bias),
@@ -131,7 +138,7 @@ class DeviceRollout(object):
             # fused in the library (mm_sample_actions): softmax -> cdf -> search, Philox uniform per agent, one
             # pass over 24 B/agent instead of five elementwise / scan kernels over fp64 temporaries
             logp = logp.contiguous()
-            actions = torch.empty(E * N, dtype=torch.int32, device=obs.device)
+            actions = dst if dst is not None else torch.empty(E * N, dtype=torch.int32, device=obs.device)
             clib = self.env.clib
             stream = self.env._stream()
             clib.check(clib.lib.mm_sample_actions(logp.data_ptr(), E * N, self.n_a, self.sample_seed,
@@ -141,7 +148,11 @@ class DeviceRollout(object):
         cdf = logp.exp().double().cumsum(-1)
         cdf = cdf / cdf[:, -1:]
         u = torch.rand(E * N, 1, dtype=torch.float64, device=obs.device, generator=self.generator)
-        return (cdf <= u).sum(-1).clamp_(max=self.n_a - 1).view(E, N).to(torch.int32)
+        a = (cdf <= u).sum(-1).clamp_(max=self.n_a - 1).to(torch.int32)
+        if dst is not None:
+            dst.copy_(a)
+            a = dst
+        return a.view(E, N)
 
     @torch.no_grad()
     def interact(self):
@@ -183,18 +194,22 @@ class DeviceRollout(object):
         actions = torch.empty(T, E, N, dtype=torch.int32, device=dev)
         rewards = torch.empty(T, E, N, dtype=torch.float64, device=dev)
         dones = torch.empty(T, E, dtype=torch.uint8, device=dev)
-        speed_sum = torch.zeros(E, dtype=torch.float64, device=dev)
-        min_headway = torch.full((E,), float("inf"), dtype=torch.float64, device=dev)
+        speeds = torch.empty(T, E, dtype=torch.float64, device=dev)
+        headways = torch.empty(T, E, dtype=torch.float64, device=dev)
         states[0] = self.obs
         obs = states[0]
+        regional = self.reward_type == "regionalR"
         for t in range(T):
-            a = self.act(obs)
-            obs, global_reward, done, info = env.step(a, obs_out=states[t + 1])
-            actions[t] = a
-            rewards[t] = info["regional_rewards"] if self.reward_type == "regionalR" else global_reward.unsqueeze(-1).expand(E, N)
-            dones[t] = done
-            speed_sum += info["average_speed"]
-            min_headway = torch.minimum(min_headway, info["min_headway"])
+            # every per-step quantity lands in its [t] slot straight from the two launches (policy + step): no copy kernels
+            a = self.act(obs, out=actions[t])
+            slots = {"done": dones[t], "average_speed": speeds[t], "min_headway": headways[t]}
+            if regional:
+                slots["regional_rewards"] = rewards[t]
+            obs, global_reward, _, _ = env.step(a, obs_out=states[t + 1], out=slots)
+            if not regional:
+                rewards[t] = global_reward.unsqueeze(-1).expand(E, N)
+        speed_sum = speeds.sum(0)
+        min_headway = headways.min(0).values
         self.obs = obs.clone()
         # bootstrap value for envs still mid-episode (marl/mappo.py:147-150); 0 where the last step ended one
         final_value = torch.zeros(E, N, dtype=torch.float64, device=dev)
@@ -204,9 +219,12 @@ class DeviceRollout(object):
             one_hot = (fa.unsqueeze(-1) == torch.arange(self.n_a, device=dev, dtype=fa.dtype)).float()
             val = self.critic(obs.reshape(E * N, S).float(), one_hot.view(E * N, self.n_a)).view(E, N).double()
             final_value = torch.where(dones[-1].bool().unsqueeze(-1), final_value, val)
-        if self.reward_scale > 0:
-            rewards = rewards / self.reward_scale  # :152-153
-        returns = discount_rewards(rewards, dones, final_value, self.gamma)
+        # reward scaling (:152-153) + _discount_reward (:364-370) in one launch (mm_discount_returns; `discount_rewards`
+        # above is the same arithmetic in torch ops, 3 launches per step of the rollout)
+        returns = torch.empty_like(rewards)
+        clib = env.clib
+        clib.check(clib.lib.mm_discount_returns(rewards.data_ptr(), dones.data_ptr(), final_value.contiguous().data_ptr(), T, E, N,
+                                                float(self.gamma), float(self.reward_scale), returns.data_ptr(), env._stream()))
         return {"states": states[:T], "actions": actions, "returns": returns, "dones": dones,
                 "average_speed": speed_sum / T, "min_headway": min_headway}
 

@@ -165,26 +165,40 @@ class BatchedMergeEnv(object):
                                                  self._stream()), self._h)
         return self.obs, self.avail
 
-    def step(self, actions, obs_out=None):
+    def step(self, actions, obs_out=None, out=None):
         """MergeEnv.step (merge_env_v1.py:126-166) for every env; actions int32 [E, N] in 0..4.
         obs_out: optional caller buffer (same shape / dtype / device as self.obs, contiguous) the new
-        observation is written to instead of self.obs -- a rollout hands over its states[t + 1] slot."""
+        observation is written to instead of self.obs -- a rollout hands over its states[t + 1] slot.
+        out: optional {key: tensor} for keys of the info dict (same shape / dtype / device as self.out[key], contiguous):
+        this step writes those outputs there instead of into self.out -- a rollout hands over rewards[t], dones[t], ...
+        and saves a copy kernel per quantity and step; the returned info carries the given tensors under those keys."""
         abi.check_supervisor(self.config.get("safety_guarantee"))
         if actions.dtype != torch.int32 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(self.device, torch.int32).contiguous()
         assert actions.numel() == self.E * self.N
-        obs = self.obs
+        obs, info = self.obs, self.out
         if obs_out is not None:
             assert obs_out.shape == self.obs.shape and obs_out.dtype == self.obs.dtype and obs_out.device == self.obs.device \
                 and obs_out.is_contiguous()
             obs = obs_out
             self._step_out.obs = obs.data_ptr()
+        if out:
+            for k, t in out.items():  # (validate everything before any pointer of the call structure changes)
+                ref = self.out[k]  # (KeyError: not an output of this env, or one it was built without)
+                assert t.shape == ref.shape and t.dtype == ref.dtype and t.device == ref.device and t.is_contiguous(), k
+            info = dict(self.out)
+            for k, t in out.items():
+                setattr(self._step_out, k, t.data_ptr())
+                info[k] = t
         try:
             self.clib.check(self.clib.lib.mm_step(self._h, _ptr(actions), C.byref(self._step_out),
                                                   self._stream()), self._h)
         finally:
             self._step_out.obs = self.obs.data_ptr()
-        return obs, self.out["reward"], self.out["done"], self.out
+            for k in out or ():
+                if k in self.out:
+                    setattr(self._step_out, k, self.out[k].data_ptr())
+        return obs, info["reward"], info["done"], info
 
     # -- checkpoint / resume --------------------------------------------------------------
     def state_dict(self):

@@ -1900,6 +1900,28 @@ int32_t orc_set_threads(int32_t n) { if (n > 0) omp_set_num_threads(n); return o
 int32_t orc_set_threads(int32_t n) { (void)n; return 1; }
 #endif
 
+/* marl/mappo.py:147-156,364-370: reward scaling + discounted returns of a rollout (see include/mm_abi.h) */
+int32_t mm_discount_returns(const double *rewards, const uint8_t *dones, const double *final_value, int32_t T,
+                            int64_t n_env, int32_t n_agent, double gamma, double reward_scale, double *returns,
+                            MMStream stream) {
+  (void)stream;
+  if (!rewards || !dones || !final_value || !returns || T < 0 || n_env < 0 || n_agent < 1) return MM_ERR_INVALID_ARG;
+  const int64_t A = n_env * n_agent;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < A; i++) {
+    const int64_t e = i / n_agent;
+    double running = final_value[i];
+    for (int t = T - 1; t >= 0; t--) {
+      double r = rewards[(int64_t)t * A + i];
+      if (reward_scale > 0) r = r / reward_scale;
+      if (dones[(int64_t)t * n_env + e]) running = 0.0;
+      running = running * gamma + r;
+      returns[(int64_t)t * A + i] = running;
+    }
+  }
+  return MM_OK;
+}
+
 /* marl/mappo.py:220-236 exploration_action / action for a batch (see include/mm_abi.h).  Always uses the
  * bit-reproducible exp of mm_math.h so that the HIP library draws the same actions from the same key. */
 int32_t mm_sample_actions(const float *logp, int64_t n, int32_t n_a, uint64_t seed, uint64_t *counter,

@@ -342,3 +342,72 @@ def test_evaluate_refuses_an_env_without_the_outputs_it_reads():
     with pytest.raises(ValueError, match="agents_info"):
         ro.evaluate(seeds=[1, 2])
     assert torch.equal(env.state, before) and env.auto_reset
+
+
+def test_step_writes_requested_outputs_into_caller_slots():
+    """step(out={key: tensor}): that step writes those outputs into the caller's tensors (a rollout's rewards[t], dones[t],
+    ...) and nowhere else; everything else -- state, the other outputs, later steps -- is what a twin without slots gives."""
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125,
+              cbf_tau=0.5, seed=4, auto_reset=True)
+    a_env, b_env = oracle_env.OracleEnv(6, 4, **kw), oracle_env.OracleEnv(6, 4, **kw)
+    a_env.reset(); b_env.reset()
+    g = torch.Generator().manual_seed(1)
+    T = 5
+    rew = torch.full((T, 6, 4), -9.0, dtype=torch.float64)
+    don = torch.full((T, 6), 7, dtype=torch.uint8)
+    for t in range(T):
+        act = torch.randint(0, 5, (6, 4), generator=g, dtype=torch.int32)
+        before = b_env.out["regional_rewards"].clone()
+        _, ra, da, ia = a_env.step(act)
+        _, rb, db, ib = b_env.step(act, out={"regional_rewards": rew[t], "done": don[t]})
+        assert torch.equal(rew[t], ia["regional_rewards"]) and torch.equal(don[t], da) and db is don[t] or torch.equal(db, don[t])
+        assert ib["regional_rewards"].data_ptr() == rew[t].data_ptr()
+        assert torch.equal(b_env.out["regional_rewards"], before), "the env's own buffer was written although a slot was given"
+        assert torch.equal(ra, rb) and torch.equal(a_env.state, b_env.state) and torch.equal(ia["agents_rewards"], ib["agents_rewards"])
+    _, _, d2, i2 = b_env.step(act)  # without slots the env's own buffers are the outputs again
+    assert d2.data_ptr() == b_env.out["done"].data_ptr() and i2["regional_rewards"].data_ptr() == b_env.out["regional_rewards"].data_ptr()
+    with pytest.raises(KeyError):
+        b_env.step(act, out={"no_such_output": rew[0]})
+    with pytest.raises(AssertionError):
+        b_env.step(act, out={"done": torch.zeros(6, dtype=torch.float64)})
+
+
+def _discount_case(seed, T=37, E=9, N=5):
+    g = torch.Generator().manual_seed(seed)
+    rewards = (torch.rand(T, E, N, dtype=torch.float64, generator=g) - 0.3) * 7
+    dones = (torch.rand(T, E, generator=g) < 0.08).to(torch.uint8)
+    final = torch.randn(E, N, dtype=torch.float64, generator=g)
+    return rewards, dones, final
+
+
+@pytest.mark.parametrize("scale", [20.0, 0.0])
+def test_discount_returns_entry_equals_the_torch_chain(scale):
+    """mm_discount_returns (CPU twin here, HIP in the GPU leg) == the reward scaling + discount_rewards chain of torch ops, bit
+    for bit (same operations in the same order: r / scale, running * gamma + r), incl. a `done` at the last step."""
+    from marl_mass_amd.rollout import discount_rewards
+    rewards, dones, final = _discount_case(3)
+    dones[-1, 0] = 1
+    want = discount_rewards(rewards / scale if scale > 0 else rewards, dones, final, 0.99)
+    clib = oracle_env.library()
+    got = torch.empty_like(rewards)
+    assert clib.lib.mm_discount_returns(rewards.data_ptr(), dones.data_ptr(), final.data_ptr(), rewards.shape[0], rewards.shape[1],
+                                        rewards.shape[2], 0.99, scale, got.data_ptr(), None) == 0
+    assert torch.equal(got, want)
+    assert clib.lib.mm_discount_returns(None, dones.data_ptr(), final.data_ptr(), 1, 1, 1, 0.99, scale, got.data_ptr(), None) != 0
+
+
+@pytest.mark.gpu
+def test_discount_returns_entry_on_gpu():
+    from marl_mass_amd import hip_library
+    from marl_mass_amd.rollout import discount_rewards
+    rewards, dones, final = _discount_case(5, T=100, E=777, N=8)
+    want = discount_rewards(rewards / 20.0, dones, final, 0.99)
+    r, d, f = rewards.cuda(), dones.cuda(), final.cuda()
+    got = torch.empty_like(r)
+    assert hip_library().lib.mm_discount_returns(r.data_ptr(), d.data_ptr(), f.data_ptr(), 100, 777, 8, 0.99, 20.0, got.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(got.cpu(), want)
+    # in place (returns may alias rewards)
+    assert hip_library().lib.mm_discount_returns(r.data_ptr(), d.data_ptr(), f.data_ptr(), 100, 777, 8, 0.99, 20.0, r.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(r.cpu(), want)
