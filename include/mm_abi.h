@@ -125,7 +125,8 @@ typedef struct MMConfig {
   int32_t action_masking;       /* config["action_masking"] (abstract.py:200-207,474-481) */
   int32_t auto_reset;           /* 1: step() re-spawns finished envs with the device RNG */
   int32_t obs_f64;              /* 0: obs written as float32, 1: float64 (reference dtype) */
-  int32_t debug_flags;          /* bit0: force the literal serial shield sweep (validation / A-B timing) */
+  int32_t debug_flags;          /* bit0: force the literal serial shield sweep; bit1: step in power-of-two lane groups only (no
+                                   6- / 12-lane layout for N = 5..6 / 9..12).  Validation / A-B timing: same results either way */
   double collision_reward;      /* COLLISION_REWARD 200 */
   double high_speed_reward;     /* HIGH_SPEED_REWARD 1  */
   double headway_cost;          /* HEADWAY_COST 4       */

@@ -63,6 +63,7 @@ struct DevState {
 //   MM_TU=2  only those, with conservative SGPR spilling (DESIGN.md "toolchain note"),
 //   MM_TU=3  only the MM_QP_IPM fidelity-mode step kernels (IPM = true: the general kernels with the QP solved by
 //            cvxopt's interior-point algorithm, include/mm_qp.h), same flags as TU 2.
+//   MM_TU=4  only the CAV-only exact-mode step kernels in the 6- / 12-lane rotation layouts (kPow2 below).
 // MM_TU=0 (default) is the single-TU form used by the tuning / diagnostic builds.
 #ifndef MM_TU
 #define MM_TU 0
@@ -136,6 +137,45 @@ MM_DEV void for_partners_impl(F &f) {
 template <int G, class F>
 MM_DEV void for_partners(F f) { for_partners_impl<1, G>(f); }
 
+// Group layouts.  A power-of-two group (2, 4, 8, 16 lanes) pairs lane a with a ^ m and exchanges by DPP (above).  The
+// step kernels of CAV-only batches also come with 6- and 12-lane groups (N = 5..6 and 9..12: ten or five envs per wave
+// instead of eight or four, and 5 / 11 partners per loop instead of 7 / 15): there partner m of lane a is (a + m) mod G
+// and the exchange goes through the LDS crossbar (ds_bpermute).  A wave holds 64 / G whole groups; with 6 or 12 lanes its
+// last 4 lanes belong to no env.  Every exchange in the kernels is written as "what partner m holds", never as a message
+// prepared for a specific reader, so the two pairings are interchangeable (the one message-style exchange, the 16-lane
+// classification, is not compiled for the rotation layouts: they use the LDS mailbox like the 8-lane groups).
+template <int G> constexpr bool kPow2 = (G & (G - 1)) == 0;
+template <int M, int G>
+MM_DEV int pidx(int a) {  // creation index of partner M of the vehicle with index a
+  if constexpr (kPow2<G>) return a ^ M;
+  else return a + M >= G ? a + M - G : a + M;
+}
+template <int G>
+MM_DEV int pidx_rt(int a, int m) {  // the same for a run-time m in 0..G-1
+  if constexpr (kPow2<G>) return a ^ m;
+  else return a + m >= G ? a + m - G : a + m;
+}
+template <int M, int G>
+MM_DEV int plane(int lane, int a) {  // lane (or LDS column) of partner M; `lane` = the caller's own lane / column
+  if constexpr (kPow2<G>) return lane ^ M;
+  else return lane - a + pidx<M, G>(a);
+}
+template <int G>
+MM_DEV int plane_rt(int lane, int a, int m) {
+  if constexpr (kPow2<G>) return lane ^ m;
+  else return lane - a + pidx_rt<G>(a, m);
+}
+template <int M, int G>
+MM_DEV int px_i(int v, int a) {
+  if constexpr (kPow2<G>) return dppx_i<M>(v);
+  else return shfl_i(v, plane<M, G>(lane_id(), a));
+}
+template <int M, int G>
+MM_DEV double px_d(double v, int a) {
+  if constexpr (kPow2<G>) return dppx_d<M>(v);
+  else return shfl_d(v, plane<M, G>(lane_id(), a));
+}
+
 template <int G>
 MM_DEV unsigned group_ballot(bool p, int gb) {
   unsigned long long b = __ballot(p);
@@ -150,7 +190,12 @@ MM_DEV void atomic_min_d(double *addr, double val) {  // CAS loop: valid for any
   } while (assumed != old);
 }
 template <int G>
-MM_DEV double group_min_d(double v) {
+MM_DEV double group_min_d(double v, int a) {
+  if constexpr (!kPow2<G>) {  // rotation layout: every partner's value once
+    double r = v;
+    for_partners<G>([&](auto mc) { r = fmin(r, px_d<decltype(mc)::value, G>(v, a)); });
+    return r;
+  }
   if constexpr (G >= 2) v = fmin(v, dppx_d<1>(v));
   if constexpr (G >= 4) v = fmin(v, dppx_d<2>(v));
   if constexpr (G >= 8) v = fmin(v, dppx_d<7>(v));  // after xor 1,2 every quad is uniform: xor 7 == xor 4
@@ -451,9 +496,9 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
     key[0] = 0;
     for_partners<G>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      const int pl = lane ^ m;
+      const int pl = plane<m, G>(lane, a);
       double px = mb[0 * 64 + pl], py = mb[1 * 64 + pl];
-      bool pp = dppx_i<m>((int)v.present) != 0;
+      bool pp = px_i<m, G>((int)v.present, a) != 0;
       double dx = px - v.x, dy = py - v.y;
       bool close = pp && (dx * dx + dy * dy) < kT180;  // norm < PERCEPTION_DISTANCE, sqrt-free
       key[m] = close ? fabs((px - sx) - (v.x - sx)) : INFINITY;
@@ -467,7 +512,7 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
     for (int m = 1; m < G; m++)
 #pragma unroll
       for (int m2 = m + 1; m2 < G; m2++) {
-        const bool m2_first = key[m2] < key[m] || (key[m2] == key[m] && (a ^ m2) < (a ^ m));
+        const bool m2_first = key[m2] < key[m] || (key[m2] == key[m] && pidx_rt<G>(a, m2) < pidx_rt<G>(a, m));
         rank[m] += m2_first ? 1 : 0;
         rank[m2] += m2_first ? 0 : 1;
       }
@@ -482,7 +527,7 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       have[q] = sel[q] != 0;
-      const int pl = lane ^ sel[q];  // (no row: my own column, masked below)
+      const int pl = plane_rt<G>(lane, a, sel[q]);  // (no row: my own column, masked below)
       row[q][0] = mb[0 * 64 + pl] - v.x; row[q][1] = mb[1 * 64 + pl] - v.y;
       row[q][2] = mb[2 * 64 + pl] - vx; row[q][3] = mb[3 * 64 + pl] - vy;
       if (KIND == MM_ENV_V1) {
@@ -528,7 +573,10 @@ MM_DEV void observe(const DevCfg &c, const Veh &v, int a, int gb, long long i, b
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const long long e0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x - lane) / G;  // first env of this wave (lane l of the launch holds env l / G; a shift, not a 64-bit division by N)
+      // first env of this wave (lane l of the launch holds env l / G: a shift, not a 64-bit division by N; rotation layouts:
+      // 64 / G whole groups per wave)
+      const long long wave_lane0 = (long long)blockIdx.x * blockDim.x + threadIdx.x - lane;
+      const long long e0 = kPow2<G> ? wave_lane0 / G : (wave_lane0 >> 6) * (64 / G);
       long long nenv = (long long)c.E - e0;
       nenv = nenv < 0 ? 0 : (nenv > 64 / G ? 64 / G : nenv);
       const int total = (int)nenv * c.N * S;
@@ -918,10 +966,16 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
   constexpr bool kSerialOnly = MIXED;
 #endif
 #endif
+  static_assert(kPow2<G> || (!MIXED && !IPM && MM_STEP_BLOCK == 64), "rotation layouts: CAV-only exact-mode step kernels, one wave per workgroup");
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long e = gtid / G;
-  const int a = (int)(gtid % G);
-  const int gb = lane_id() & ~(G - 1);
+  // power-of-two groups tile the launch seamlessly; 6- / 12-lane groups: 64 / G whole groups per wave, its last 4 lanes idle
+  // (the idle tail lanes address the wave's last group with a >= G: whatever they read is a real lane's, they own no env and
+  // no vehicle slot -- e = E, a >= N -- and no group's ballot window contains them)
+  constexpr int kTail = kPow2<G> ? 64 : (64 / G) * G;
+  const bool tail = lane_id() >= kTail;
+  const int gb = kPow2<G> ? (lane_id() & ~(G - 1)) : (tail ? kTail - G : lane_id() - lane_id() % G);
+  const int a = kPow2<G> ? (int)(gtid % G) : lane_id() - gb;
+  const long long e = kPow2<G> ? gtid / G : (tail ? (long long)st.E : (gtid >> 6) * (64 / G) + lane_id() / G);
   const bool valid = e < st.E && a < st.N;
   const long long i = e * st.N + a;
   const long long A = st.A;
@@ -967,8 +1021,11 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
   // partners' classification reads instead of a DPP exchange per field)
   enum { C_B = 0, C_H1X = 8, C_H1VX, C_H2X, C_H2VX, C_SSTEER, C_SACC, C_TSPEED, C_A = 15, C_GU0 = 23, C_GU1 = 24, C_PRE = 25, C_MSGW = 29 };
   // (16-lane groups keep the DPP exchange: 5 more slots would cost them a wave per CU -- measured 0.456 -> 0.504 ms at N = 12)
-  constexpr bool kMailbox = G <= 8;
-  constexpr int kColdB = kMailbox ? 30 : 25;
+  constexpr bool kMailbox = G <= 8 || !kPow2<G>;  // (the DPP form below exchanges reader-specific messages: power-of-two groups only)
+  // (rotation layouts: the rank word rides in the unused high half of the pose-code slot -- 40 slots = 20 KB at G = 12, the
+  // eighth wave of a CU)
+  constexpr bool kPackMsg = !kPow2<G>;
+  constexpr int kColdB = kMailbox ? (kPackMsg ? 29 : 30) : 25;
   // candidates occupy 8 slots each (x, y, h, pose code [int], cos h, steering, g.vx, sin h); unshielded kernels use only slots
   // 8..14 (+ the obs staging: 15 slots); the sort keys are a parallel-form temporary
   constexpr bool kRoomy = false;  // (round 1 parked cos(heading) / g.vx in LDS as well: no longer measurable, 0.332 ms either way)
@@ -998,9 +1055,9 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
     if (SHIELDED || MIXED) {
       for_partners<G>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
-        double px = dppx_d<m>(v.x);
-        bool pp = dppx_i<m>((int)live) != 0;
-        rank += (pp && (px > v.x || (px == v.x && (a ^ m) < a))) ? 1 : 0;
+        double px = px_d<m, G>(v.x, a);
+        bool pp = px_i<m, G>((int)live, a) != 0;
+        rank += (pp && (px > v.x || (px == v.x && pidx<m, G>(a) < a))) ? 1 : 0;
       });
     }
     v.tspeed = s_cold[C_TSPEED][tid];
@@ -1209,7 +1266,9 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
           // both candidate images in LDS, a partner picks what it sees of me by address -- my committed post-state if I step
           // before it, else my pre-step pose -- instead of receiving 3 doubles + 2 ints through DPP and select chains
           if constexpr (kMailbox) {
-            cold_i(C_MSGW, tid) = (live ? rank : 99) | (use_B ? 256 : 0);
+            const int my_word = (live ? rank : 99) | (use_B ? 256 : 0);
+            if constexpr (kPackMsg) ((int *)&s_cold[C_PRE + 3][tid])[1] = my_word;
+            else cold_i(C_MSGW, tid) = my_word;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1220,13 +1279,15 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
           int j_ol = -1, j_oa = -1, j_oar = -1;
           for_partners<G>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
-            const int p = a ^ m;
+            const int p = pidx<m, G>(a);
             int p_rank, opk;
             double ox, oy, oh;
             bool i_first;
             if constexpr (kMailbox) {
-              const int pl = tid ^ m;
-              const int pw = cold_i(C_MSGW, pl);
+              const int pl = plane<m, G>(tid, a);
+              int pw;
+              if constexpr (kPackMsg) pw = ((const int *)&s_cold[C_PRE + 3][pl])[1];
+              else pw = cold_i(C_MSGW, pl);
               p_rank = pw & 255;
               i_first = live && rank < p_rank;                      // I step before this partner
               // its pose as I see it: the committed post-state if it steps before me, else the pre-step pose
@@ -1269,7 +1330,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
             int pos_ol = 0, pos_oa = 0, pos_oar = 0;
 #pragma unroll
             for (int m = 1; m < G; m++) {
-              const int p = a ^ m;
+              const int p = pidx_rt<G>(a, m);
               const double km = s_cold[kColdB + m - 1][tid];
               pos_ol += (km < k_ol || (km == k_ol && p < j_ol)) ? 1 : 0;
               pos_oa += (km < k_oa || (km == k_oa && p < j_oa)) ? 1 : 0;
@@ -1433,7 +1494,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
         int srank = 0;
         for_partners<G>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
-          srank += (dppx_i<m>(shield_on ? rank : 99) < rank) ? 1 : 0;
+          srank += (px_i<m, G>(shield_on ? rank : 99, a) < rank) ? 1 : 0;
         });
         for (int j = 0; j < st.N; j++) {
           const unsigned sel = group_ballot<G>(shield_on && srank == j, gb);
@@ -1459,8 +1520,8 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
           int pos = 0;
           for_partners<G>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
-            double kp = dppx_d<m>(rl.key);
-            pos += (kp < rl.key || (kp == rl.key && (a ^ m) < a)) ? 1 : 0;
+            double kp = px_d<m, G>(rl.key, a);
+            pos += (kp < rl.key || (kp == rl.key && pidx<m, G>(a) < a)) ? 1 : 0;
           });
           const bool in5 = rl.key < INFINITY && pos < 5;
           const unsigned none = 0x3FFu;
@@ -1483,10 +1544,20 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
             w = m0 | m1 << 10 | m2 << 20;
             if (MIXED) f_tw = min(f_tw, (unsigned)dppx_i<m>((int)f_tw));
           };
-          if constexpr (G >= 2) red(std::integral_constant<int, 1>{});
-          if constexpr (G >= 4) red(std::integral_constant<int, 2>{});
-          if constexpr (G >= 8) red(std::integral_constant<int, 7>{});
-          if constexpr (G >= 16) red(std::integral_constant<int, 8>{});
+          if constexpr (kPow2<G>) {
+            if constexpr (G >= 2) red(std::integral_constant<int, 1>{});
+            if constexpr (G >= 4) red(std::integral_constant<int, 2>{});
+            if constexpr (G >= 8) red(std::integral_constant<int, 7>{});
+            if constexpr (G >= 16) red(std::integral_constant<int, 8>{});
+          } else {  // rotation layout (CAV-only kernels): the minimum over every partner's word, field by field
+            const unsigned w0 = w;
+            for_partners<G>([&](auto mc) {
+              const unsigned o = (unsigned)px_i<decltype(mc)::value, G>((int)w0, a);
+              const unsigned m0 = min(w & 0x3FFu, o & 0x3FFu), m1 = min((w >> 10) & 0x3FFu, (o >> 10) & 0x3FFu),
+                             m2 = min((w >> 20) & 0x3FFu, (o >> 20) & 0x3FFu);
+              w = m0 | m1 << 10 | m2 << 20;
+            });
+          }
           f_ol = w & 0x3FFu; f_oa = (w >> 10) & 0x3FFu; f_oar = (w >> 20) & 0x3FFu;
           const bool has_tw = MIXED && f_tw != none;
           if (has_tw) f_oa = f_tw & ~1u;  // s_oa = that HDV's (shifted) record; constrain_adj set below
@@ -1574,11 +1645,11 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
     unsigned need = 0;  // bit p: partner with creation index p; bit G: the obstacle
     for_partners<G>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      double px = dppx_d<m>(v.x), py = dppx_d<m>(v.y), ph = dppx_d<m>(v.h);
-      bool pp = dppx_i<m>((int)live) != 0;
+      double px = px_d<m, G>(v.x, a), py = px_d<m, G>(v.y, a), ph = px_d<m, G>(v.h, a);
+      bool pp = px_i<m, G>((int)live, a) != 0;
       double dx = px - v.x, dy = py - v.y;
       const bool near = live & pp & !((dx * dx + dy * dy) > kU5);  // norm > LENGTH pre-check, sqrt-free
-      need |= (near & boxes_may_touch(dx, dy, v.h, ph, 0.9 * kVehLength / 2, 0.9 * kVehWidth / 2)) ? 1u << (a ^ m) : 0u;
+      need |= (near & boxes_may_touch(dx, dy, v.h, ph, 0.9 * kVehLength / 2, 0.9 * kVehWidth / 2)) ? 1u << pidx<m, G>(a) : 0u;
     });
     {
       double dx = kObstX - v.x, dy = kObstY - v.y;
@@ -1674,11 +1745,11 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
   unsigned hdv_bits = 0;                           // which vehicles of the env are HDVs
   for_partners<G>([&](auto mc) {
     constexpr int m = decltype(mc)::value;
-    const int p = a ^ m;
-    double px = dppx_d<m>(v.x);
-    int pk = dppx_i<m>(v.present ? v.lane : 15);
+    const int p = pidx<m, G>(a);
+    double px = px_d<m, G>(v.x, a);
+    int pk = px_i<m, G>(v.present ? v.lane : 15, a);
     bool pp = pk != 15;
-    if (MIXED) hdv_bits |= (dppx_i<m>((int)hdv) != 0) ? (1u << p) : 0u;
+    if (MIXED) hdv_bits |= (px_i<m, G>((int)hdv, a) != 0) ? (1u << p) : 0u;
     if (pp && pk == v.lane && px > v.x) { double dd = px - v.x; if (dd < hd) hd = dd; }
     if (pp && v.lane != MM_LANE_BC1 && pk == nl && px > v.x) { double dd = px - v.x; if (dd < hd) hd = dd; }
     const bool in_own = pp && ((allow_own >> pk) & 1u), in_side = pp && ((allow_side >> pk) & 1u);
@@ -1742,7 +1813,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
     double vx = v.v * cpsi;  // cos(heading), carried along
     th = h2d / (vx > 1 ? vx : 1);
   }
-  const double min_headway = group_min_d<G>(th);
+  const double min_headway = group_min_d<G>(th, a);
   if (e < st.E) { n_merge = st.I[MM_E_N_MERGE * st.E + e]; episode = st.I[MM_E_EPISODE * st.E + e]; }
   double merge_pct = __builtin_nan("");
   if (done) {
@@ -2115,9 +2186,38 @@ struct MMHandle_ {
 
 // waves one step launch starts (launch_step_t rounds the grid up to whole MM_STEP_BLOCK-thread blocks): every one of them
 // stores its 64-byte slot of the metrics partial buffer
+// waves of a step launch in the power-of-two layout: the size of the metrics partial buffer (a launch in a rotation layout
+// has fewer waves -- more envs per wave -- never more)
 static long long step_launch_waves(const MMHandle h) {
   const long long threads = (long long)h->E * group_size(h->N);
   return (threads + MM_STEP_BLOCK - 1) / MM_STEP_BLOCK * (MM_STEP_BLOCK / 64);
+}
+// Lanes per env group of the step launch the CURRENT configuration selects.  CAV-only exact-mode batches of 5..6 / 9..12
+// vehicles run the 6- / 12-lane rotation layouts (kPow2 above: 10 / 5 envs per wave instead of 8 / 4, 5 / 11 partners per
+// loop instead of 7 / 15); everything else -- HDVs, steer_vel, the interior-point mode -- the power-of-two groups.
+static int step_group(const MMHandle h) {
+  const int g = group_size(h->N);
+#if defined(MM_ONLY_G)  // tuning builds: the one group size that was compiled
+  (void)g;
+  return MM_ONLY_G;
+#elif defined(MM_NO_LANES)
+  return g;
+#else
+  const MMConfig &c = h->cfg;
+  const bool general = c.n_hdv > 0 || (c.traffic_density > 0 && c.mixed_traffic != 0) ||
+                       (c.env_kind == MM_ENV_V1 && c.lateral_control == MM_LATERAL_STEER_VEL);  // == needs_general(h)
+  const bool ipm = c.env_kind == MM_ENV_V1 && c.shield != MM_SHIELD_NONE && c.qp_solver == MM_QP_IPM;
+  if (general || ipm || (c.debug_flags & 2)) return g;  // (debug_flags bit1: validation / A-B timing against the power-of-two groups)
+  if (h->N == 5 || h->N == 6) return 6;
+  if (h->N >= 9 && h->N <= 12) return 12;
+  return g;
+#endif
+}
+static long long step_launch_waves_now(const MMHandle h) {
+  const int g = step_group(h);
+  if ((g & (g - 1)) == 0) return step_launch_waves(h);
+  const long long epw = 64 / g;
+  return (h->E + epw - 1) / epw;
 }
 #if MM_TU <= 1
 static uint64_t align256(uint64_t x) { return (x + 255u) & ~(uint64_t)255u; }
@@ -2229,7 +2329,8 @@ static int poll_latch(MMHandle h, int word, MMStream stream) {
   return MM_ERR_INVALID_ARG;
 }
 static void launch_metrics_flush(MMHandle h, hipStream_t s, int reset) {
-  const long long waves = step_launch_waves(h);
+  // per-step fold: the rows the launch just wrote; deferred fold: the whole buffer (rows nothing added to hold the identity)
+  const long long waves = reset ? step_launch_waves(h) : step_launch_waves_now(h);
   hipLaunchKernelGGL(metrics_flush_kernel, dim3((unsigned)((waves + kFlushWaves - 1) / kFlushWaves)), dim3(256), 0, s,
                      h->metrics_partial, waves, h->metrics, reset);
 }
@@ -2365,7 +2466,8 @@ extern "C" int32_t mm_observe(MMHandle h, void *obs, uint8_t *avail, MMStream st
 template <int G, int KIND, int SHIELD, bool MIXED, bool IPM = false>
 static void launch_step_t(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   const long long threads = (long long)h->E * G;
-  const unsigned grid = (unsigned)((threads + MM_STEP_BLOCK - 1) / MM_STEP_BLOCK);
+  const unsigned grid = kPow2<G> ? (unsigned)((threads + MM_STEP_BLOCK - 1) / MM_STEP_BLOCK)
+                                 : (unsigned)((h->E + 64 / G - 1) / (64 / G));  // rotation layouts: 64 / G whole groups per wave
   if (out->trace)
     hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, MIXED, IPM, true>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dev_cfg(h), dev_state(h),
                        actions, *out, h->metrics ? h->metrics_partial : nullptr);
@@ -2406,8 +2508,21 @@ static void launch_step_ipm_g(MMHandle h, const int32_t *actions, const MMStepOu
 #if MM_TU != 0
 void mm_launch_step_general(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s);
 void mm_launch_step_ipm(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s);
+void mm_launch_step_lanes(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s);
 #endif
-#if MM_TU == 2
+#if MM_TU == 0 || MM_TU == 4
+#if MM_TU == 0
+static
+#endif
+void mm_launch_step_lanes(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+#ifndef MM_ONLY_G
+  if (g == 6) launch_step_m<6, false>(h, actions, out, s);
+  else launch_step_m<12, false>(h, actions, out, s);
+#endif
+}
+#endif
+#if MM_TU == 4
+#elif MM_TU == 2
 void mm_launch_step_general(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   switch (group_size(h->N)) {
     case 2: launch_step_m<2, true>(h, actions, out, s); break;
@@ -2463,10 +2578,11 @@ extern "C" int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *
 #ifdef MM_ONLY_G  // tuning builds: one group size, seconds to compile
   launch_step_g<MM_ONLY_G>(h, actions, out, s);
 #else
-  switch (group_size(h->N)) {
+  switch (step_group(h)) {
     case 2: launch_step_g<2>(h, actions, out, s); break;
     case 4: launch_step_g<4>(h, actions, out, s); break;
     case 8: launch_step_g<8>(h, actions, out, s); break;
+    case 6: case 12: mm_launch_step_lanes(h, step_group(h), actions, out, s); break;
     default: launch_step_g<16>(h, actions, out, s); break;
   }
 #endif

@@ -206,6 +206,39 @@ def test_parallel_sweep_equals_literal_serial_sweep(safety, N):
         assert torch.equal(fast.obs, slow.obs) and torch.equal(fast.out["reward"], slow.out["reward"]), t
 
 
+@pytest.mark.parametrize("env_id,safety,N,E", [("merge-multi-agent-v1", "cbf-cav", 6, 333), ("merge-multi-agent-v1", "cbf-cav", 11, 37),
+                                               ("merge-multi-agent-v1", "cbf-cav", 12, 256), ("merge-multi-agent-v1", "cbf-avs_cint", 5, 1),
+                                               ("merge-multi-agent-v1", "cbf-avs_cint", 9, 100), ("merge-multi-agent-v1", "none", 10, 64),
+                                               ("merge-multi-agent-v0", "none", 6, 77), ("merge-multi-agent-v0", "none", 11, 10)])
+def test_six_and_twelve_lane_groups_equal_the_power_of_two_groups(env_id, safety, N, E):
+    """CAV-only batches of 5..6 / 9..12 vehicles step in 6- / 12-lane groups (partner (a + m) mod G through ds_bpermute, ten /
+    five envs per wave with four idle tail lanes) -- the same batch stepped in 8- / 16-lane groups (debug_flags bit1) must
+    give identical bits everywhere: state, trace, observations, every output, the rollout metrics; batch sizes that leave
+    the last wave partly empty, an env alone in its launch, action masking on (v0)."""
+    kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125 if safety != "none" else 0.0,
+              cbf_tau=0.5, seed=99, auto_reset=True, trace=True)
+    lanes, pow2 = _gpu_env(E, N, **kw), _gpu_env(E, N, debug_flags=2, **kw)
+    ml, mp = lanes.enable_metrics(), pow2.enable_metrics(deferred=True)
+    ol, al = lanes.reset(); op, ap = pow2.reset()
+    assert torch.equal(ol, op) and torch.equal(al, ap)
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    p = torch.tensor([0.25, 0.25, 0.25, 0.15, 0.1], device="cuda:0")
+    for t in range(130):
+        a = torch.multinomial(p, E * N, True, generator=g).view(E, N).int()
+        ol, rl, dl, il = lanes.step(a)
+        op, rp, dp, ip = pow2.step(a)
+        assert torch.equal(lanes.u8, pow2.u8) and torch.equal(lanes.env_i32, pow2.env_i32), t
+        assert torch.equal(lanes.f64.nan_to_num(nan=-7.0), pow2.f64.nan_to_num(nan=-7.0)), t
+        assert torch.equal(lanes.trace.nan_to_num(nan=-7.0), pow2.trace.nan_to_num(nan=-7.0)), t
+        assert torch.equal(ol, op) and torch.equal(rl, rp) and torch.equal(dl, dp), t
+        for k in il:
+            x, y = il[k], ip[k]
+            assert torch.equal(x.nan_to_num(nan=-7.0) if x.is_floating_point() else x, y.nan_to_num(nan=-7.0) if y.is_floating_point() else y), (t, k)
+    pow2.flush_metrics()
+    torch.cuda.synchronize()
+    assert torch.equal(ml[[1, 4, 6, 7]], mp[[1, 4, 6, 7]]) and torch.allclose(ml, mp, rtol=1e-12, atol=0)
+
+
 def test_float32_obs_matches_float64():
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
               cbf_eta=0.03125, cbf_tau=0.5, seed=7)

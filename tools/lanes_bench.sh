@@ -1,0 +1,11 @@
+set -o pipefail
+cd $GRAFT_REPO_ROOT
+run() { python3 bench.py --no-cpu-baseline --no-fidelity-line "$@" 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-60s %.4f ms  %.3e /s' % ('$*', d['ms_per_step'], d['value']))"; }
+run --traffic-density 1 --agents 6
+run --traffic-density 3 --agents 11
+run --envs 32768 --agents 12
+run --envs 65536 --agents 6
+run --envs 65536 --agents 6 --shield hss
+run --envs 65536 --agents 6 --shield none
+run --envs 32768 --agents 12 --shield none
+run --envs 32768 --agents 10
