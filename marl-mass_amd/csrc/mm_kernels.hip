@@ -63,7 +63,7 @@ struct DevState {
 //   MM_TU=2  only those, with conservative SGPR spilling (DESIGN.md "toolchain note"),
 //   MM_TU=3  only the MM_QP_IPM fidelity-mode step kernels (IPM = true: the general kernels with the QP solved by
 //            cvxopt's interior-point algorithm, include/mm_qp.h), same flags as TU 2.
-//   MM_TU=4  only the CAV-only exact-mode step kernels in the 6- / 12-lane rotation layouts (kPow2 below).
+//   MM_TU=4  only the exact-mode step kernels in the 6- / 12-lane rotation layouts (kPow2 below).
 // MM_TU=0 (default) is the single-TU form used by the tuning / diagnostic builds.
 #ifndef MM_TU
 #define MM_TU 0
@@ -138,7 +138,7 @@ template <int G, class F>
 MM_DEV void for_partners(F f) { for_partners_impl<1, G>(f); }
 
 // Group layouts.  A power-of-two group (2, 4, 8, 16 lanes) pairs lane a with a ^ m and exchanges by DPP (above).  The
-// step kernels of CAV-only batches also come with 6- and 12-lane groups (N = 5..6 and 9..12: ten or five envs per wave
+// exact-mode step kernels also come with 6- and 12-lane groups (N = 5..6 and 9..12: ten or five envs per wave
 // instead of eight or four, and 5 / 11 partners per loop instead of 7 / 15): there partner m of lane a is (a + m) mod G
 // and the exchange goes through the LDS crossbar (ds_bpermute).  A wave holds 64 / G whole groups; with 6 or 12 lanes its
 // last 4 lanes belong to no env.  Every exchange in the kernels is written as "what partner m holds", never as a message
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
   constexpr bool kSerialOnly = MIXED;
 #endif
 #endif
-  static_assert(kPow2<G> || (!MIXED && !IPM && MM_STEP_BLOCK == 64), "rotation layouts: CAV-only exact-mode step kernels, one wave per workgroup");
+  static_assert(kPow2<G> || (!IPM && MM_STEP_BLOCK == 64), "rotation layouts: exact-mode step kernels, one wave per workgroup");
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   // power-of-two groups tile the launch seamlessly; 6- / 12-lane groups: 64 / G whole groups per wave, its last 4 lanes idle
   // (the idle tail lanes address the wave's last group with a >= G: whatever they read is a real lane's, they own no env and
@@ -1100,15 +1100,15 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
         unsigned abort_mask = 0;  // partners that would make me abort IF they target my target lane
         for_partners<G>([&](auto mc) {
           constexpr int m = decltype(mc)::value;
-          const int p = a ^ m;
-          const bool bp = dppx_i<m>((int)live) != 0;
-          const double bx = dppx_d<m>(v.x), by = dppx_d<m>(v.y), bk = dppx_d<m>(koff);
+          const int p = pidx<m, G>(a);
+          const bool bp = px_i<m, G>((int)live, a) != 0;
+          const double bx = px_d<m, G>(v.x, a), by = px_d<m, G>(v.y, a), bk = px_d<m, G>(koff, a);
           if (acting) {
             neighbour_update(lf0, s_me, bp, bx, by, bk, p, n0);
             if (try_mobil) neighbour_update(lf1, s_side, bp, bx, by, bk, p, n1);
           }
           if (__any(acting && lc_branch && same_road)) {  // the ongoing-lane-change abort test (:193-206) needs the partner as a Body
-            Body b = {bp, false, bx, by, 0.0, dppx_d<m>(v.v), 0.0, dppx_i<m>(v.lane), dppx_d<m>(spsi), dppx_d<m>(cpsi), bk};
+            Body b = {bp, false, bx, by, 0.0, px_d<m, G>(v.v, a), 0.0, px_i<m, G>(v.lane, a), px_d<m, G>(spsi, a), px_d<m, G>(cpsi, a), bk};
             if (acting && lc_branch && same_road && b.present && b.lane != my_tl) {
               const double sx = lane_sx(v.lane);
               const double d = (b.x - sx) - (v.x - sx);
@@ -1151,8 +1151,8 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
           bool hit = false;
           for_partners<G>([&](auto mc) {
             constexpr int m = decltype(mc)::value;
-            const int p = a ^ m;
-            const int pk = dppx_i<m>(rank | tl_pre << 4 | tl_post << 8);
+            const int p = pidx<m, G>(a);
+            const int pk = px_i<m, G>(rank | tl_pre << 4 | tl_post << 8, a);
             const int p_tl = ((pk & 15) < rank) ? ((pk >> 8) & 7) : ((pk >> 4) & 7);  // acted before me?
             hit = hit || (((abort_mask >> p) & 1u) && p_tl == my_tl);
           });
@@ -1549,13 +1549,14 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
             if constexpr (G >= 4) red(std::integral_constant<int, 2>{});
             if constexpr (G >= 8) red(std::integral_constant<int, 7>{});
             if constexpr (G >= 16) red(std::integral_constant<int, 8>{});
-          } else {  // rotation layout (CAV-only kernels): the minimum over every partner's word, field by field
-            const unsigned w0 = w;
+          } else {  // rotation layout: the minimum over every partner's word, field by field
+            const unsigned w0 = w, tw0 = f_tw;
             for_partners<G>([&](auto mc) {
               const unsigned o = (unsigned)px_i<decltype(mc)::value, G>((int)w0, a);
               const unsigned m0 = min(w & 0x3FFu, o & 0x3FFu), m1 = min((w >> 10) & 0x3FFu, (o >> 10) & 0x3FFu),
                              m2 = min((w >> 20) & 0x3FFu, (o >> 20) & 0x3FFu);
               w = m0 | m1 << 10 | m2 << 20;
+              if (MIXED) f_tw = min(f_tw, (unsigned)px_i<decltype(mc)::value, G>((int)tw0, a));
             });
           }
           f_ol = w & 0x3FFu; f_oa = (w >> 10) & 0x3FFu; f_oar = (w >> 20) & 0x3FFu;
@@ -2192,9 +2193,9 @@ static long long step_launch_waves(const MMHandle h) {
   const long long threads = (long long)h->E * group_size(h->N);
   return (threads + MM_STEP_BLOCK - 1) / MM_STEP_BLOCK * (MM_STEP_BLOCK / 64);
 }
-// Lanes per env group of the step launch the CURRENT configuration selects.  CAV-only exact-mode batches of 5..6 / 9..12
-// vehicles run the 6- / 12-lane rotation layouts (kPow2 above: 10 / 5 envs per wave instead of 8 / 4, 5 / 11 partners per
-// loop instead of 7 / 15); everything else -- HDVs, steer_vel, the interior-point mode -- the power-of-two groups.
+// Lanes per env group of the step launch the CURRENT configuration selects.  Exact-mode batches of 5..6 / 9..12
+// vehicles (CAV-only or mixed traffic) run the 6- / 12-lane rotation layouts (kPow2 above: 10 / 5 envs per wave instead of 8 / 4, 5 / 11 partners per
+// loop instead of 7 / 15); the interior-point mode keeps the power-of-two groups.
 static int step_group(const MMHandle h) {
   const int g = group_size(h->N);
 #if defined(MM_ONLY_G)  // tuning builds: the one group size that was compiled
@@ -2207,7 +2208,8 @@ static int step_group(const MMHandle h) {
   const bool general = c.n_hdv > 0 || (c.traffic_density > 0 && c.mixed_traffic != 0) ||
                        (c.env_kind == MM_ENV_V1 && c.lateral_control == MM_LATERAL_STEER_VEL);  // == needs_general(h)
   const bool ipm = c.env_kind == MM_ENV_V1 && c.shield != MM_SHIELD_NONE && c.qp_solver == MM_QP_IPM;
-  if (general || ipm || (c.debug_flags & 2)) return g;  // (debug_flags bit1: validation / A-B timing against the power-of-two groups)
+  (void)general;
+  if (ipm || (c.debug_flags & 2)) return g;  // (debug_flags bit1: validation / A-B timing against the power-of-two groups)
   if (h->N == 5 || h->N == 6) return 6;
   if (h->N >= 9 && h->N <= 12) return 12;
   return g;
@@ -2516,8 +2518,13 @@ static
 #endif
 void mm_launch_step_lanes(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
 #ifndef MM_ONLY_G
-  if (g == 6) launch_step_m<6, false>(h, actions, out, s);
-  else launch_step_m<12, false>(h, actions, out, s);
+  if (needs_general(h)) {  // HDVs / steer_vel: the kernels that carry IDM / MOBIL
+    if (g == 6) launch_step_m<6, true>(h, actions, out, s);
+    else launch_step_m<12, true>(h, actions, out, s);
+  } else {
+    if (g == 6) launch_step_m<6, false>(h, actions, out, s);
+    else launch_step_m<12, false>(h, actions, out, s);
+  }
 #endif
 }
 #endif

@@ -206,17 +206,23 @@ def test_parallel_sweep_equals_literal_serial_sweep(safety, N):
         assert torch.equal(fast.obs, slow.obs) and torch.equal(fast.out["reward"], slow.out["reward"]), t
 
 
-@pytest.mark.parametrize("env_id,safety,N,E", [("merge-multi-agent-v1", "cbf-cav", 6, 333), ("merge-multi-agent-v1", "cbf-cav", 11, 37),
-                                               ("merge-multi-agent-v1", "cbf-cav", 12, 256), ("merge-multi-agent-v1", "cbf-avs_cint", 5, 1),
-                                               ("merge-multi-agent-v1", "cbf-avs_cint", 9, 100), ("merge-multi-agent-v1", "none", 10, 64),
-                                               ("merge-multi-agent-v0", "none", 6, 77), ("merge-multi-agent-v0", "none", 11, 10)])
-def test_six_and_twelve_lane_groups_equal_the_power_of_two_groups(env_id, safety, N, E):
-    """CAV-only batches of 5..6 / 9..12 vehicles step in 6- / 12-lane groups (partner (a + m) mod G through ds_bpermute, ten /
+@pytest.mark.parametrize("env_id,safety,N,E,n_hdv,lateral", [
+    ("merge-multi-agent-v1", "cbf-cav", 6, 333, 0, "steer"), ("merge-multi-agent-v1", "cbf-cav", 11, 37, 0, "steer"),
+    ("merge-multi-agent-v1", "cbf-cav", 12, 256, 0, "steer"), ("merge-multi-agent-v1", "cbf-avs_cint", 5, 1, 0, "steer"),
+    ("merge-multi-agent-v1", "cbf-avs_cint", 9, 100, 0, "steer"), ("merge-multi-agent-v1", "none", 10, 64, 0, "steer"),
+    ("merge-multi-agent-v0", "none", 6, 77, 0, "steer"), ("merge-multi-agent-v0", "none", 11, 10, 0, "steer"),
+    # the general kernels: HDVs (IDM / MOBIL, the digital-twin slot of the literal sweep) and steer_vel
+    ("merge-multi-agent-v1", "cbf-cav", 6, 333, 3, "steer"), ("merge-multi-agent-v1", "cbf-cav", 11, 77, 5, "steer"),
+    ("merge-multi-agent-v1", "cbf-avs_cint", 12, 64, 6, "steer"), ("merge-multi-agent-v1", "none", 9, 50, 4, "steer"),
+    ("merge-multi-agent-v0", "none", 5, 41, 2, "steer"), ("merge-multi-agent-v1", "cbf-cav", 10, 45, 0, "steer_vel"),
+    ("merge-multi-agent-v1", "cbf-avs_cint", 6, 129, 2, "steer_vel")])
+def test_six_and_twelve_lane_groups_equal_the_power_of_two_groups(env_id, safety, N, E, n_hdv, lateral):
+    """Batches of 5..6 / 9..12 vehicles step in 6- / 12-lane groups (partner (a + m) mod G through ds_bpermute, ten /
     five envs per wave with four idle tail lanes) -- the same batch stepped in 8- / 16-lane groups (debug_flags bit1) must
     give identical bits everywhere: state, trace, observations, every output, the rollout metrics; batch sizes that leave
-    the last wave partly empty, an env alone in its launch, action masking on (v0)."""
-    kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125 if safety != "none" else 0.0,
-              cbf_tau=0.5, seed=99, auto_reset=True, trace=True)
+    the last wave partly empty, an env alone in its launch, action masking on (v0), mixed traffic, steer_vel."""
+    kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5, "lateral_control": lateral},
+              cbf_eta=0.03125 if safety != "none" else 0.0, cbf_tau=0.5, seed=99, auto_reset=True, trace=True, n_hdv=n_hdv)
     lanes, pow2 = _gpu_env(E, N, **kw), _gpu_env(E, N, debug_flags=2, **kw)
     ml, mp = lanes.enable_metrics(), pow2.enable_metrics(deferred=True)
     ol, al = lanes.reset(); op, ap = pow2.reset()

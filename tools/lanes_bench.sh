@@ -9,3 +9,6 @@ run --envs 65536 --agents 6 --shield hss
 run --envs 65536 --agents 6 --shield none
 run --envs 32768 --agents 12 --shield none
 run --envs 32768 --agents 10
+run --traffic-density 1 --agents 6 --mixed-traffic
+run --traffic-density 3 --agents 11 --mixed-traffic
+run --envs 65536 --agents 6 --hdv 3
