@@ -141,7 +141,7 @@ def ipm_mode_line(args, dev, E, N, cfg, kw, ring, steps=12):
                     "loop; bit-identical to the reference-side restatement that produced the ipm_* tapes"}
 
 
-def workload_traffic(E, N, shield, env_id, qp_solver):
+def workload_traffic(E, N, shield, env_id, qp_solver, hdv=0, density=0, pow2=False):
     """HBM bytes per launch from the committed PMC passes (profiles/traffic.json: one row per profiled workload, written
     from tools/profile.sh runs of this command); None for a workload that was not profiled."""
     try:
@@ -149,8 +149,9 @@ def workload_traffic(E, N, shield, env_id, qp_solver):
         rows = tj["workloads"] if "workloads" in tj else [tj]
         for r in rows:
             w = r["workload"]
-            if (w["envs_per_gpu"], w["agents"], w["shield"], w["env_id"], w.get("qp_solver", "exact"), w.get("hdv", 0)) == \
-                    (E, N, shield, env_id, qp_solver, 0):
+            if (w["envs_per_gpu"], w["agents"], w["shield"], w["env_id"], w.get("qp_solver", "exact"), w.get("hdv", 0),
+                    w.get("traffic_density", 0), bool(w.get("pow2_groups", False))) == \
+                    (E, N, shield, env_id, qp_solver, hdv, density, bool(pow2)):
                 return r["bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -184,6 +185,8 @@ def main():
                          "then the slot capacity (>= 6 / 8 / 11) of a ragged batch and agent-steps count the vehicles actually present "
                          "(the reference's training distribution; not the headline workload)")
     ap.add_argument("--mixed-traffic", action="store_true", help="with --traffic-density: CAVs + IDM/MOBIL HDVs (traffic_type=mixed)")
+    ap.add_argument("--pow2-groups", action="store_true", help="A-B timing: step in power-of-two lane groups only (debug_flags bit1; N = 5..6 / "
+                                                               "9..12 otherwise run in 6- / 12-lane groups)")
     ap.add_argument("--all-outputs", action="store_true", help="also write agents_info / action_mask / crashed every step (30 B per agent "
                                                                 "that B_alg does not count and the rollout loop does not read)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -229,7 +232,7 @@ def main():
         first_env, E, E_total = rank * args.envs, args.envs, args.envs * world
     cfg = {"safety_guarantee": SHIELDS[args.shield], "HEADWAY_TIME": 0.5 if args.shield != "none" else 1.2}
     kw = dict(cbf_eta=0.03125 if args.shield != "none" else 0.0, cbf_tau=cfg["HEADWAY_TIME"], seed=1000,
-              auto_reset=True, obs_f64=args.obs_f64, n_hdv=args.hdv, qp_solver=args.qp_solver)
+              auto_reset=True, obs_f64=args.obs_f64, n_hdv=args.hdv, qp_solver=args.qp_solver, debug_flags=2 if args.pow2_groups else 0)
     if args.traffic_density:
         cfg.update({"traffic_density": args.traffic_density, "traffic_type": "mixed" if args.mixed_traffic else "cav",
                     "mixed_traffic": args.mixed_traffic})
@@ -323,7 +326,8 @@ def main():
         achieved = E * N * b_alg / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch and VALU instructions per wave from the committed PMC passes of this workload
         # (profiles/traffic.json: one row per profiled workload); null for a workload that was not profiled
-        traffic = workload_traffic(E, N, args.shield, args.env_id, args.qp_solver) if not (args.hdv or args.traffic_density) else None
+        traffic = None if args.mixed_traffic else workload_traffic(E, N, args.shield, args.env_id, args.qp_solver, args.hdv,
+                                                                   args.traffic_density, args.pow2_groups)
         # secondary reading (the kernel is VALU-issue bound): instructions from the committed
         # SQ_INSTS_VALU pass x 4 issue cycles per wave64 instruction, against 1024 SIMDs at the 2.4 GHz peak clock
         valu = None
@@ -365,7 +369,7 @@ def main():
                                       QP_MODE_NOTE[args.qp_solver] if args.shield != "none" else "no shield",
                                       cfg["HEADWAY_TIME"], " (OFF)" if args.no_stagger else "",
                                       (", of which %d HDVs per env" % args.hdv) if args.hdv else ""),
-                       "envs_total": E_total, "envs_per_gpu": E, "agents": N, "obs_dtype": "f64" if args.obs_f64 else "f32",
+                       "envs_total": E_total, "envs_per_gpu": E, "agents": N, "traffic_density": args.traffic_density, "pow2_groups": bool(args.pow2_groups), "obs_dtype": "f64" if args.obs_f64 else "f32",
                        "qp_solver": args.qp_solver,
                        "tolerance": {"north_star": "1e-5 on float state vs the reference's QP (cvxopt interior-point iterate)",
                                      "exact": "closed-form KKT point = the true minimiser; differs from the interior-point iterate by "

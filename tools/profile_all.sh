@@ -9,10 +9,12 @@ declare -A ARGS=(
   [ipm]="--qp-solver ipm"
   [hss_ipm]="--qp-solver ipm --shield hss"
   [mixed44]="--hdv 4"
-  [g16]="--envs 32768 --agents 12"
+  [g16]="--envs 32768 --agents 12 --pow2-groups"
+  [lanes12]="--envs 32768 --agents 12"
+  [density3]="--traffic-density 3 --agents 11"
   [small8192]="--envs 8192"
 )
-TAGS=("$@"); [ ${#TAGS[@]} -gt 0 ] || TAGS=(headline ipm mixed44 g16 small8192)
+TAGS=("$@"); [ ${#TAGS[@]} -gt 0 ] || TAGS=(headline ipm mixed44 lanes12 density3 g16 small8192)
 for t in "${TAGS[@]}"; do
   steps=200; case "$t" in ipm|hss_ipm) steps=30;; esac
   echo "== profile $t: bench.py ${ARGS[$t]}"
