@@ -63,7 +63,7 @@ struct DevState {
 //   MM_TU=2  only those, with conservative SGPR spilling (DESIGN.md "toolchain note"),
 //   MM_TU=3  only the MM_QP_IPM fidelity-mode step kernels (IPM = true: the general kernels with the QP solved by
 //            cvxopt's interior-point algorithm, include/mm_qp.h), same flags as TU 2.
-//   MM_TU=4  only the exact-mode step kernels in the 6- / 12-lane rotation layouts (kPow2 below).
+//   MM_TU=4 / 5  only the exact-mode / the interior-point step kernels in the 6- / 12-lane rotation layouts (kPow2 below).
 // MM_TU=0 (default) is the single-TU form used by the tuning / diagnostic builds.
 #ifndef MM_TU
 #define MM_TU 0
@@ -966,7 +966,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
   constexpr bool kSerialOnly = MIXED;
 #endif
 #endif
-  static_assert(kPow2<G> || (!IPM && MM_STEP_BLOCK == 64), "rotation layouts: exact-mode step kernels, one wave per workgroup");
+  static_assert(kPow2<G> || MM_STEP_BLOCK == 64, "rotation layouts: one wave per workgroup");
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   // power-of-two groups tile the launch seamlessly; 6- / 12-lane groups: 64 / G whole groups per wave, its last 4 lanes idle
   // (the idle tail lanes address the wave's last group with a >= G: whatever they read is a real lane's, they own no env and
@@ -2195,7 +2195,7 @@ static long long step_launch_waves(const MMHandle h) {
 }
 // Lanes per env group of the step launch the CURRENT configuration selects.  Exact-mode batches of 5..6 / 9..12
 // vehicles (CAV-only or mixed traffic) run the 6- / 12-lane rotation layouts (kPow2 above: 10 / 5 envs per wave instead of 8 / 4, 5 / 11 partners per
-// loop instead of 7 / 15); the interior-point mode keeps the power-of-two groups.
+// loop instead of 7 / 15).
 static int step_group(const MMHandle h) {
   const int g = group_size(h->N);
 #if defined(MM_ONLY_G)  // tuning builds: the one group size that was compiled
@@ -2207,9 +2207,8 @@ static int step_group(const MMHandle h) {
   const MMConfig &c = h->cfg;
   const bool general = c.n_hdv > 0 || (c.traffic_density > 0 && c.mixed_traffic != 0) ||
                        (c.env_kind == MM_ENV_V1 && c.lateral_control == MM_LATERAL_STEER_VEL);  // == needs_general(h)
-  const bool ipm = c.env_kind == MM_ENV_V1 && c.shield != MM_SHIELD_NONE && c.qp_solver == MM_QP_IPM;
   (void)general;
-  if (ipm || (c.debug_flags & 2)) return g;  // (debug_flags bit1: validation / A-B timing against the power-of-two groups)
+  if (c.debug_flags & 2) return g;  // (debug_flags bit1: validation / A-B timing against the power-of-two groups)
   if (h->N == 5 || h->N == 6) return 6;
   if (h->N >= 9 && h->N <= 12) return 12;
   return g;
@@ -2511,6 +2510,18 @@ static void launch_step_ipm_g(MMHandle h, const int32_t *actions, const MMStepOu
 void mm_launch_step_general(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s);
 void mm_launch_step_ipm(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s);
 void mm_launch_step_lanes(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s);
+void mm_launch_step_lanes_ipm(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s);
+#endif
+#if MM_TU == 0 || MM_TU == 5
+#if MM_TU == 0
+static
+#endif
+void mm_launch_step_lanes_ipm(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+#ifndef MM_ONLY_G
+  if (g == 6) launch_step_ipm_g<6>(h, actions, out, s);
+  else launch_step_ipm_g<12>(h, actions, out, s);
+#endif
+}
 #endif
 #if MM_TU == 0 || MM_TU == 4
 #if MM_TU == 0
@@ -2518,7 +2529,9 @@ static
 #endif
 void mm_launch_step_lanes(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
 #ifndef MM_ONLY_G
-  if (needs_general(h)) {  // HDVs / steer_vel: the kernels that carry IDM / MOBIL
+  if (h->cfg.env_kind == MM_ENV_V1 && h->cfg.shield != MM_SHIELD_NONE && h->cfg.qp_solver == MM_QP_IPM) {  // interior-point mode
+    mm_launch_step_lanes_ipm(h, g, actions, out, s);
+  } else if (needs_general(h)) {  // HDVs / steer_vel: the kernels that carry IDM / MOBIL
     if (g == 6) launch_step_m<6, true>(h, actions, out, s);
     else launch_step_m<12, true>(h, actions, out, s);
   } else {
@@ -2528,7 +2541,7 @@ void mm_launch_step_lanes(MMHandle h, int g, const int32_t *actions, const MMSte
 #endif
 }
 #endif
-#if MM_TU == 4
+#if MM_TU == 4 || MM_TU == 5
 #elif MM_TU == 2
 void mm_launch_step_general(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   switch (group_size(h->N)) {

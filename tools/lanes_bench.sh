@@ -12,3 +12,7 @@ run --envs 32768 --agents 10
 run --traffic-density 1 --agents 6 --mixed-traffic
 run --traffic-density 3 --agents 11 --mixed-traffic
 run --envs 65536 --agents 6 --hdv 3
+run --traffic-density 1 --agents 6 --qp-solver ipm --steps 30 --warmup 3
+run --traffic-density 1 --agents 6 --qp-solver ipm --steps 30 --warmup 3 --pow2-groups
+run --traffic-density 3 --agents 11 --qp-solver ipm --steps 20 --warmup 3
+run --traffic-density 3 --agents 11 --qp-solver ipm --steps 20 --warmup 3 --pow2-groups
