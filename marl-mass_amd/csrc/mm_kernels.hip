@@ -58,9 +58,9 @@ struct DevState {
   int E, N;
 };
 
-// Translation units.  The library is built from this one source compiled twice (Makefile):
+// Translation units.  The library is built from this one source compiled five times (Makefile):
 //   MM_TU=1  everything except the "general" step kernels (MIXED = true: HDVs and/or steer_vel),
-//   MM_TU=2  only those, with conservative SGPR spilling (DESIGN.md "toolchain note"),
+//   MM_TU=2  only those (round 1 built them with conservative SGPR spilling, DESIGN.md "toolchain note"; no longer),
 //   MM_TU=3  only the MM_QP_IPM fidelity-mode step kernels (IPM = true: the general kernels with the QP solved by
 //            cvxopt's interior-point algorithm, include/mm_qp.h), same flags as TU 2.
 //   MM_TU=4 / 5  only the exact-mode / the interior-point step kernels in the 6- / 12-lane rotation layouts (kPow2 below).

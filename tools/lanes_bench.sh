@@ -1,3 +1,5 @@
+#!/bin/bash
+# GPU box: bench lines of the workloads that run in 6- / 12-lane env groups (N = 5..6, 9..12), with --pow2-groups for A-B.
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 run() { python3 bench.py --no-cpu-baseline --no-fidelity-line "$@" 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('%-60s %.4f ms  %.3e /s' % ('$*', d['ms_per_step'], d['value']))"; }
