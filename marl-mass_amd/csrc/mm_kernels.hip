@@ -2193,9 +2193,8 @@ static long long step_launch_waves(const MMHandle h) {
   const long long threads = (long long)h->E * group_size(h->N);
   return (threads + MM_STEP_BLOCK - 1) / MM_STEP_BLOCK * (MM_STEP_BLOCK / 64);
 }
-// Lanes per env group of the step launch the CURRENT configuration selects.  Exact-mode batches of 5..6 / 9..12
-// vehicles (CAV-only or mixed traffic) run the 6- / 12-lane rotation layouts (kPow2 above: 10 / 5 envs per wave instead of 8 / 4, 5 / 11 partners per
-// loop instead of 7 / 15).
+// Lanes per env group of the step launch: batches of 5..6 / 9..12 vehicles run the 6- / 12-lane rotation layouts (kPow2
+// above: 10 / 5 envs per wave instead of 8 / 4, 5 / 11 partners per loop instead of 7 / 15), the others power-of-two groups.
 static int step_group(const MMHandle h) {
   const int g = group_size(h->N);
 #if defined(MM_ONLY_G)  // tuning builds: the one group size that was compiled
@@ -2204,11 +2203,7 @@ static int step_group(const MMHandle h) {
 #elif defined(MM_NO_LANES)
   return g;
 #else
-  const MMConfig &c = h->cfg;
-  const bool general = c.n_hdv > 0 || (c.traffic_density > 0 && c.mixed_traffic != 0) ||
-                       (c.env_kind == MM_ENV_V1 && c.lateral_control == MM_LATERAL_STEER_VEL);  // == needs_general(h)
-  (void)general;
-  if (c.debug_flags & 2) return g;  // (debug_flags bit1: validation / A-B timing against the power-of-two groups)
+  if (h->cfg.debug_flags & 2) return g;  // (debug_flags bit1: validation / A-B timing against the power-of-two groups)
   if (h->N == 5 || h->N == 6) return 6;
   if (h->N >= 9 && h->N <= 12) return 12;
   return g;
