@@ -12,9 +12,11 @@ declare -A ARGS=(
   [g16]="--envs 32768 --agents 12 --pow2-groups"
   [lanes12]="--envs 32768 --agents 12"
   [density3]="--traffic-density 3 --agents 11"
+  [density1]="--traffic-density 1 --agents 6"
+  [density3mixed]="--traffic-density 3 --agents 11 --mixed-traffic"
   [small8192]="--envs 8192"
 )
-TAGS=("$@"); [ ${#TAGS[@]} -gt 0 ] || TAGS=(headline ipm mixed44 lanes12 density3 g16 small8192)
+TAGS=("$@"); [ ${#TAGS[@]} -gt 0 ] || TAGS=(headline ipm mixed44 lanes12 density1 density3 density3mixed g16 small8192)
 for t in "${TAGS[@]}"; do
   steps=200; case "$t" in ipm|hss_ipm) steps=30;; esac
   echo "== profile $t: bench.py ${ARGS[$t]}"
