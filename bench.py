@@ -293,6 +293,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         kern_ms = sum(a.elapsed_time(b) for a, b in ev.values()) / len(ev)  # HIP events on the launch stream
+        env.poll_errors()  # (outside the timed region) a latched check_bounds / bad action / kernel loop guard voids the measurement: raise
         return elapsed, kern_ms, metrics, env, ring
 
     elapsed, kern_ms, metrics, env, ring = measure(E, first_env, args.steps, args.warmup)

@@ -222,7 +222,8 @@ class DeviceRollout(object):
         # reward scaling (:152-153) + _discount_reward (:364-370) in one launch (mm_discount_returns; `discount_rewards`
         # above is the same arithmetic in torch ops, 3 launches per step of the rollout)
         returns = torch.empty_like(rewards)
-        clib = env.clib
+        clib = env.clib  # (errors the reference raises inside step() are latched on the device: the training loop polls them,
+        #                   env.poll_errors(), where it synchronises anyway -- a poll per rollout here would break hipGraph capture)
         clib.check(clib.lib.mm_discount_returns(rewards.data_ptr(), dones.data_ptr(), final_value.contiguous().data_ptr(), T, E, N,
                                                 float(self.gamma), float(self.reward_scale), returns.data_ptr(), env._stream()))
         return {"states": states[:T], "actions": actions, "returns": returns, "dones": dones,
