@@ -191,10 +191,12 @@ MM_DEV void atomic_min_d(double *addr, double val) {  // CAS loop: valid for any
 }
 template <int G>
 MM_DEV double group_min_d(double v, int a) {
-  if constexpr (!kPow2<G>) {  // rotation layout: every partner's value once
-    double r = v;
-    for_partners<G>([&](auto mc) { r = fmin(r, px_d<decltype(mc)::value, G>(v, a)); });
-    return r;
+  if constexpr (!kPow2<G>) {  // rotation layout: doubling steps around the ring of G <= 16 lanes (overlapping windows: a minimum does not mind)
+    v = fmin(v, px_d<1, G>(v, a));
+    v = fmin(v, px_d<2, G>(v, a));
+    if constexpr (G > 4) v = fmin(v, px_d<4, G>(v, a));
+    if constexpr (G > 8) v = fmin(v, px_d<8, G>(v, a));
+    return v;
   }
   if constexpr (G >= 2) v = fmin(v, dppx_d<1>(v));
   if constexpr (G >= 4) v = fmin(v, dppx_d<2>(v));
@@ -1549,15 +1551,21 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
             if constexpr (G >= 4) red(std::integral_constant<int, 2>{});
             if constexpr (G >= 8) red(std::integral_constant<int, 7>{});
             if constexpr (G >= 16) red(std::integral_constant<int, 8>{});
-          } else {  // rotation layout: the minimum over every partner's word, field by field
-            const unsigned w0 = w, tw0 = f_tw;
-            for_partners<G>([&](auto mc) {
-              const unsigned o = (unsigned)px_i<decltype(mc)::value, G>((int)w0, a);
-              const unsigned m0 = min(w & 0x3FFu, o & 0x3FFu), m1 = min((w >> 10) & 0x3FFu, (o >> 10) & 0x3FFu),
-                             m2 = min((w >> 20) & 0x3FFu, (o >> 20) & 0x3FFu);
-              w = m0 | m1 << 10 | m2 << 20;
-              if (MIXED) f_tw = min(f_tw, (unsigned)px_i<decltype(mc)::value, G>((int)tw0, a));
-            });
+          } else {
+            // rotation layout: doubling steps 1, 2, 4, 8 -- after them a lane holds the minimum over itself and the next 15
+            // lanes of its ring of G <= 16, i.e. over the whole group (windows overlap: harmless for a minimum)
+            auto ring = [&](auto mc) {
+              constexpr int off = decltype(mc)::value;
+              if constexpr (off < G) {
+                const unsigned o = (unsigned)px_i<off, G>((int)w, a);
+                const unsigned m0 = min(w & 0x3FFu, o & 0x3FFu), m1 = min((w >> 10) & 0x3FFu, (o >> 10) & 0x3FFu),
+                               m2 = min((w >> 20) & 0x3FFu, (o >> 20) & 0x3FFu);
+                w = m0 | m1 << 10 | m2 << 20;
+                if (MIXED) f_tw = min(f_tw, (unsigned)px_i<off, G>((int)f_tw, a));
+              }
+            };
+            ring(std::integral_constant<int, 1>{}); ring(std::integral_constant<int, 2>{});
+            ring(std::integral_constant<int, 4>{}); ring(std::integral_constant<int, 8>{});
           }
           f_ol = w & 0x3FFu; f_oa = (w >> 10) & 0x3FFu; f_oar = (w >> 20) & 0x3FFu;
           const bool has_tw = MIXED && f_tw != none;
