@@ -1854,8 +1854,9 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
   // Each env's leader lane parks its 8 contributions in its own (now dead) candidate columns of the cold slots; lanes
   // 0..7 of the wave then each sum one metric over the wave's env leaders and store (or, with mm_defer_metrics, add to)
   // the wave's slot of the partial buffer; metrics_flush_kernel -- launched right behind this kernel by mm_step, or once
-  // per rollout by mm_flush_metrics when the metrics are deferred -- folds the partials into the caller's 8 doubles.  (Round 1 used LDS atomics between two __syncthreads() + 8 global atomics per block: 15 % of a wave's
-  // lifetime parked at the barriers.)
+  // per rollout by mm_flush_metrics when the metrics are deferred -- folds the partials into the caller's 8 doubles.
+  // (Round 1 used LDS atomics between two __syncthreads() + 8 global atomics per block: 15 % of a wave's lifetime parked
+  // at the barriers.)
   if (metrics) {
     static_assert(MM_STEP_BLOCK % 64 == 0, "whole waves per workgroup");
     const bool lead = e < st.E && a == 0 && env_ok;
