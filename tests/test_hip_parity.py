@@ -403,12 +403,17 @@ def test_deferred_metrics_match_per_step_folding():
     assert torch.allclose(ma, mb, rtol=1e-12, atol=0) and float(mb[4]) == 123 * 777
 
 
-def test_full_size_bit_exact_vs_oracle():
+@pytest.mark.parametrize("E,N,density", [(65536, 8, 0), (32768, 12, 0), (65536, 6, 1), (32768, 11, 3)],
+                         ids=["headline", "12-lane-groups", "density1-6-lane", "density3-12-lane"])
+def test_full_size_bit_exact_vs_oracle(E, N, density):
     """BASELINE's headline size (65536 envs x 8 CAVs, MASS, auto-reset) for 12 steps against the
-    OpenMP oracle: every state bit, obs, reward, done of all 524 288 agents."""
-    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
-              cbf_eta=0.03125, cbf_tau=0.5, seed=1000, auto_reset=True)
-    E, N = 65536, 8
+    OpenMP oracle: every state bit, obs, reward, done of all 524 288 agents -- and the bench sizes of the 6- / 12-lane
+    group layouts: 32 768 x 12, and the reference's traffic_density 1 / 3 with the vehicle counts drawn per episode."""
+    cfg = {"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}
+    kw = dict(env_id="merge-multi-agent-v1", config=cfg, cbf_eta=0.03125, cbf_tau=0.5, seed=1000, auto_reset=True)
+    if density:
+        cfg.update({"traffic_density": density, "traffic_type": "cav", "mixed_traffic": False})
+        kw["draw_counts"] = True
     oracle_env.library().lib.orc_set_threads(16)
     gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
     gpu.reset()
