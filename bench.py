@@ -232,7 +232,7 @@ def main():
         first_env, E, E_total = rank * args.envs, args.envs, args.envs * world
     cfg = {"safety_guarantee": SHIELDS[args.shield], "HEADWAY_TIME": 0.5 if args.shield != "none" else 1.2}
     kw = dict(cbf_eta=0.03125 if args.shield != "none" else 0.0, cbf_tau=cfg["HEADWAY_TIME"], seed=1000,
-              auto_reset=True, obs_f64=args.obs_f64, n_hdv=args.hdv, qp_solver=args.qp_solver, debug_flags=2 if args.pow2_groups else 0)
+              auto_reset=True, obs_f64=args.obs_f64, n_hdv=args.hdv, qp_solver=args.qp_solver, debug_flags=(2 if args.pow2_groups else 0) | int(os.environ.get("MM_DEBUG_FLAGS", "0")))
     if args.traffic_density:
         cfg.update({"traffic_density": args.traffic_density, "traffic_type": "mixed" if args.mixed_traffic else "cav",
                     "mixed_traffic": args.mixed_traffic})

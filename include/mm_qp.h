@@ -76,6 +76,7 @@ typedef struct MMQpState {
   double s0, s1, s2, s3, z0, z1, z2, z3;          /* slacks and multipliers */
   double d0, d1, d2, d3, di0, di1, di2, di3;      /* Nesterov-Todd scaling W = diag(d) and W^-1 ... */
   double l0, l1, l2, l3;                          /* ... lambda = W^-1 s = W z (valid from the first mm_qp_bottom on) */
+  double ax0, ax2;                                /* what the last iteration added to x0 / x2 (step * dx; mm_qp_frozen reads it) */
   int m4, iters;
 } MMQpState;
 typedef struct MMQpRes { double rx0, rx2, rz0, rz1, rz2, rz3; } MMQpRes;  /* what mm_qp_top hands to mm_qp_bottom */
@@ -153,6 +154,7 @@ MMM_FN double mm_qp_maxneg(double p0, double p1, double p2, double p3, int m4) {
 MMM_FN int mm_qp_start(MMQpState *q, double a, double h0, double h1, double h2, double h3, int rows) {
   const int m4 = rows == 4;
   q->a = a; q->m4 = m4; q->iters = 0;
+  q->ax0 = q->ax2 = INFINITY;
   q->h0 = h0; q->h1 = h1; q->h2 = h2; q->h3 = m4 ? h3 : 0.0;
   q->resz0 = fmax(1.0, sqrt(mm_qp_dot(q->h0, q->h0, q->h1, q->h1, q->h2, q->h2, q->h3, q->h3, m4)));  /* resx0 = max(1, |q|) = 1 */
   q->d0 = q->d1 = q->d2 = q->d3 = 1.0; q->di0 = q->di1 = q->di2 = q->di3 = 1.0; q->l0 = q->l1 = q->l2 = q->l3 = 1.0;
@@ -182,8 +184,68 @@ MMM_FN int mm_qp_start(MMQpState *q, double a, double h0, double h1, double h2, 
   return 1;
 }
 
+/*
+ * Frozen-iterate certificate (MM_QP_CERTIFY builds only: the HIP kernels; the oracle and the reference-side restatement
+ * always run the literal loop, so every HIP-vs-oracle parity test checks the certificate bit for bit).
+ *
+ * 0.4 % of the shield's QPs are infeasible without the slack (the CBF row cannot be met even at full braking): the solution is
+ * d = -h2 (the lower bound) with slack s > 0, the multiplier of the CBF row is ~1e18 * s, and cvxopt's dual-residual test
+ * ||P x + G'z|| <= 1e-7 can never pass on a cancellation of 2^47-sized terms -- coneqp runs to its 100-iteration cap and
+ * returns status "unknown" (cbf.py:134-140 keeps the iterate).  From iteration ~28 on those 70+ iterations change nothing that
+ * is returned: x0 sits EXACTLY on -h2, x2 is constant, and what still moves (s, z of the active rows shrinking / wiggling in
+ * their last bits, the scaling) feeds back into x only through Newton steps that are absorbed by the rounding of x + step*dx.
+ * mm_qp_frozen() recognises that state from quantities the iteration has anyway; a caller may then stop and report
+ * (x0, x2, "unknown", 100 iterations).  It returns 1 only if ALL of the following hold, each chosen so that it keeps holding:
+ *   (1) the last update of x0 and of x2 was absorbed with 20 bits to spare: |step * dx| <= 2^-75 |x| (half an ulp is
+ *       >= 2^-54 |x|).  In this regime dx0 = -dz2 + O((|rx| + 1e18 a |dz0|) / di2^2) with dz_k = s_k (1 + o(1)) of the ACTIVE rows:
+ *       it shrinks with s_k (x ~0.01 per iteration, never grows by more than the centring term, see (3)), and di2^2 >= 2^100.
+ *   (2) row 2 (-d <= h2) is active and met with equality in floating point: x0 == -h2, its residual rz2 is exactly 0 and
+ *       s2 <= 2^-70 |h2| (so fl(s2 - h2) = -h2 whatever s2 does next); row 1 is inactive (z1 <= 2^-60); each CBF row (0, and 3
+ *       with rows == 4) is either active the same way (rz == 0, s tiny, z >= 2^20) or inactive (z <= 2^-60), at least one active.
+ *       Exactly-zero residuals of the active rows mean nothing pulls x away: rz is a function of (h, x, a) alone once s is
+ *       below half an ulp of h.
+ *   (3) no underflow / overflow before the cap: s_active >= 2^-400 and d_active >= 2^-120 now; both lose <= 2^-6.7 / 2^-3.4
+ *       per iteration for at most 92 more iterations (s' = s (1 - step) + step * sigma * mu / z with step <= 1, sigma <= 1).
+ *   (4) the stopping test cannot pass before the cap.  Its dual part needs |rx0| <= 1e-7 with rx0 = fl(x0 + t),
+ *       t = ((a z0 + z1) - z2) [+ a z3]: the multipliers of the active rows are >= 2^20, so t is a sum of multiples of
+ *       g = ulp of the smallest of them (tiny terms -- inactive multipliers, <= 2^-60 -- are absorbed or add < 2^-59), i.e.
+ *       t lies on the lattice g Z up to 2^-59, and |rx0| >= dist(x0, g Z) - 2^-58.  Required: dist(x0, (g/2) Z) > 2e-7 (g/2:
+ *       the multipliers wiggle in their last bits and may cross a binade).  A QP that fails (4) (x0 within 2e-7 of the
+ *       lattice: 6e-6 of them at the usual g = 2^-5) simply iterates on.
+ * Verified bit for bit against the literal loop on every QP the reference assembled (tests/golden: 78 388, 364 capped, all
+ * certified between iteration 23 and 51) and on the oracle in every rollout / soak test.
+ */
+#ifndef MM_QP_ILOGB
+#define MM_QP_ILOGB(x) ilogb(x)
+#define MM_QP_LDEXP(x, e) ldexp(x, e)
+#define MM_QP_RINT(x) rint(x)
+#endif
+MMM_FN int mm_qp_row_state(double s, double z, double rz, double hmag) {  /* 1 active, 2 inactive, 0 neither */
+  if (rz == 0.0 && s <= 0x1p-70 * hmag && s >= 0x1p-400 && z >= 0x1p+20) return 1;
+  if (z <= 0x1p-60) return 2;
+  return 0;
+}
+MMM_FN int mm_qp_frozen(const MMQpState *q, const MMQpRes *r) {
+  if (q->iters < 8 || !(q->a > 0.0)) return 0;
+  if (!(fabs(q->ax0) <= 0x1p-75 * fabs(q->x0)) || !(fabs(q->ax2) <= 0x1p-75 * fabs(q->x2))) return 0;             /* (1) */
+  if (q->x0 != -q->h2 || mm_qp_row_state(q->s2, q->z2, r->rz2, fabs(q->h2)) != 1 || !(q->z1 <= 0x1p-60)) return 0; /* (2) */
+  const int r0 = mm_qp_row_state(q->s0, q->z0, r->rz0, fmax(fabs(q->h0), fabs(q->x2)));
+  const int r3 = q->m4 ? mm_qp_row_state(q->s3, q->z3, r->rz3, fmax(fabs(q->h3), fabs(q->x2))) : 2;
+  if (r0 == 0 || r3 == 0 || (r0 != 1 && r3 != 1)) return 0;
+  if (!(q->d2 >= 0x1p-120) || (r0 == 1 && !(q->d0 >= 0x1p-120)) || (r3 == 1 && !(q->d3 >= 0x1p-120))) return 0;    /* (3) */
+  int e = MM_QP_ILOGB(q->z2);                                                                                        /* (4) */
+  if (r0 == 1) { const int e0 = MM_QP_ILOGB(q->a * q->z0); e = e0 < e ? e0 : e; }
+  if (r3 == 1) { const int e3 = MM_QP_ILOGB(q->a * q->z3); e = e3 < e ? e3 : e; }
+  if (e < 20 || e > 200) return 0;
+  const double y = MM_QP_LDEXP(q->x0, 53 - e);  /* x0 / (g/2), exact (g/2 = 2^(e-53)) */
+  if (!(fabs(y) < 0x1p+51)) return 0;           /* the lattice is finer than x0 itself */
+  const double dist = MM_QP_LDEXP(fabs(y - MM_QP_RINT(y)), e - 53);
+  return dist > 2e-7;
+}
+
 /* Residuals of the current iterate and cvxopt's stopping test.  Returns 0: go on (call mm_qp_bottom with *r), 1: stop,
- * "optimal", 2: stop, "unknown" (iteration cap). */
+ * "optimal", 2: stop, "unknown" (iteration cap); MM_QP_CERTIFY builds also 3: stop, the iterate is frozen and the loop
+ * would run to the cap without changing it (mm_qp_frozen): report "unknown" and MM_QP_MAXITERS iterations. */
 MMM_FN int mm_qp_top(const MMQpState *q, MMQpRes *r) {
   const int m4 = q->m4;
   const double a = q->a, x0 = q->x0, x2 = q->x2, gap = q->gap;
@@ -216,6 +278,9 @@ MMM_FN int mm_qp_top(const MMQpState *q, MMQpRes *r) {
   const double pres = resz / q->resz0;
   const int met = pres <= MM_QP_FEASTOL && dres_ok && (gap <= MM_QP_ABSTOL || (have_rel && relgap <= MM_QP_RELTOL));
   if (q->iters == MM_QP_MAXITERS) return 2;  /* coneqp: the cap wins over a test met in the same iteration */
+#ifdef MM_QP_CERTIFY
+  if (!met && mm_qp_frozen(q, r)) return 3;
+#endif
   return met ? 1 : 0;
 }
 
@@ -293,8 +358,10 @@ MMM_FN int mm_qp_bottom(MMQpState *q, const MMQpRes *r) {
     sigma = sg * sg * sg;
   }
   MM_QP_PASS(1)
-  q->x0 = q->x0 + step * dx0;
-  q->x2 = q->x2 + step * dx2;
+  q->ax0 = step * dx0;
+  q->ax2 = step * dx2;
+  q->x0 = q->x0 + q->ax0;
+  q->x2 = q->x2 + q->ax2;
   MM_QP_UPDATE(0) MM_QP_UPDATE(1) MM_QP_UPDATE(2)
   if (m4) MM_QP_UPDATE(3)
   q->gap = mm_qp_dot(q->l0, q->l0, q->l1, q->l1, q->l2, q->l2, q->l3, q->l3, m4);
@@ -308,15 +375,19 @@ MMM_FN int mm_qp_ipm_cbf(double a, double h0, double h1, double h2, double h3, i
                          int *iters_out) {
   MMQpState q;
   MMQpRes r;
-  int status = 0;
+  int status = 0, certified = 0;
+  (void)certified;
   if (mm_qp_start(&q, a, h0, h1, h2, h3, rows)) {
     for (;;) {
       const int stop = mm_qp_top(&q, &r);
-      if (stop) { status = stop == 1; break; }
+      if (stop) { status = stop == 1; certified = stop == 3; break; }
       if (!mm_qp_bottom(&q, &r)) break;
     }
   }
   *d_out = q.x0; *s_out = q.x2; *iters_out = q.iters;
+#ifdef MM_QP_CERTIFY
+  if (certified) *iters_out = MM_QP_MAXITERS;
+#endif
   return status;
 }
 

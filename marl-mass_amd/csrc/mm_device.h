@@ -13,6 +13,11 @@
 #define MM_DEV __device__ __forceinline__
 #define MMM_FN __device__ __forceinline__
 #include "../../include/mm_math.h"
+// device builds stop a QP whose iterate is provably frozen instead of running it to cvxopt's iteration cap (mm_qp_frozen in
+// include/mm_qp.h: same result bits; the oracle runs the literal loop).  -DMM_QP_NO_CERTIFY: A-B timing / validation builds.
+#ifndef MM_QP_NO_CERTIFY
+#define MM_QP_CERTIFY
+#endif
 #include "../../include/mm_qp.h"  // the shield QP through cvxopt's interior-point algorithm (MM_QP_IPM)
 
 namespace mm {

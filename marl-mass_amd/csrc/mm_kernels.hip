@@ -58,7 +58,34 @@ struct DevState {
   int E, N;
 };
 
-// Translation units.  The library is built from this one source compiled five times (Makefile):
+// Hand-off buffer of the SPLIT interior-point step (device memory owned by the handle, never the caller's): with
+// qp_solver = MM_QP_IPM a CAV-only shielded batch steps as nsub + 1 launches of the "phase" form of step_kernel (lane per
+// vehicle: act / predict / commit / collide / rewards) with one launch of sweep_kernel (lane per ENV: the front-to-back
+// shield sweep with its interior-point QPs) after each act / predict.  Planes are [field][vehicle a][env e] with the env
+// index innermost: a sweep wave (64 consecutive envs) reads "field f of vehicle a" as one coalesced 512-byte line.
+enum {
+  SW_WX, SW_WY, SW_WH, SW_WHX, SW_WGU, SW_WVX,                   // what the others see of a vehicle: pre-step view, overwritten by the sweep when it commits
+  SW_V, SW_CPSI, SW_GVX, SW_ACCN, SW_H1X, SW_H1VX,               // the vehicle's own shield inputs (speed, cos heading, g.vx, nominal acceleration, state_hist[-1])
+  SW_AX, SW_AY, SW_AH, SW_ACPSI, SW_AGVX, SW_ASTEER, SW_ASPSI,   // candidate A (nominal steering): predicted post-state
+  SW_BX, SW_BY, SW_BH, SW_BCPSI, SW_BGVX, SW_BSTEER, SW_BSPSI,   // candidate B (LC-veto steering), only where META says needB
+  SW_ACC,                                                        // sweep -> phase kernel: the decided acceleration
+  SW_F_COUNT
+};
+enum { SW_WPK, SW_APK, SW_BPK, SW_META, SW_RES, SW_I_COUNT };
+// SW_META: bit0 live, bit1 shield_on, bit2 needB, bits 8..15 Vehicle flags, bits 16..23 hl_action
+// SW_RES (written by the sweep for every ego it ran): bit0 ran, bit1 veto, bit2 committed candidate B, bits 8..15 new flags
+struct SweepBuf {
+  double *F;       // [SW_F_COUNT][N][Ep]
+  int *I;          // [SW_I_COUNT][N][Ep]
+  uint8_t *order;  // [N][Ep]: creation index of the live vehicle with sweep rank r (x descending, stable), 0xFF: none
+  uint8_t *envf;   // [Ep]: the env is still stepping (no terminal sub-step so far in this policy step)
+  long long Ep;    // E rounded up to whole waves
+  int N;
+};
+MM_DEV double &sw_f(const SweepBuf &sb, int f, int a, long long e) { return sb.F[((long long)f * sb.N + a) * sb.Ep + e]; }
+MM_DEV int &sw_i(const SweepBuf &sb, int f, int a, long long e) { return sb.I[((long long)f * sb.N + a) * sb.Ep + e]; }
+
+// Translation units.  The library is built from this one source compiled six times (Makefile):
 //   MM_TU=1  everything except the "general" step kernels (MIXED = true: HDVs and/or steer_vel),
 //   MM_TU=2  only those (round 1 built them with conservative SGPR spilling, DESIGN.md "toolchain note"; no longer),
 //   MM_TU=3  only the MM_QP_IPM fidelity-mode step kernels (IPM = true: the general kernels with the QP solved by
@@ -75,6 +102,14 @@ struct DevState {
 // lane k of every wave accumulates phase k in a register; one plain store per wave at the end (no atomics in flight)
 #define MM_STAMP_WAVES (1 << 16)
 __device__ unsigned long long g_stamps_w[MM_STAMP_WAVES * 16];
+__device__ unsigned long long g_stamps_s[4096 * 8];  // sweep kernel: per wave {top, post, setup, bottom, trips, setup trips, -, -} (cycles / counts)
+#define SSTAMP(k)                                                                        \
+  do {                                                                                   \
+    unsigned long long _t = __builtin_amdgcn_s_memtime();                                \
+    if ((threadIdx.x & 63) == (k)) _t_acc += _t - _t_last;                               \
+    _t_last = __builtin_amdgcn_s_memtime();                                              \
+  } while (0)
+#define SCOUNT(k) do { if ((threadIdx.x & 63) == (k)) _t_acc += 1; } while (0)
 #define STAMP(k)                                                                         \
   do {                                                                                   \
     unsigned long long _t = __builtin_amdgcn_s_memtime();                                \
@@ -83,6 +118,8 @@ __device__ unsigned long long g_stamps_w[MM_STAMP_WAVES * 16];
   } while (0)
 #else
 #define STAMP(k) do {} while (0)
+#define SSTAMP(k) do {} while (0)
+#define SCOUNT(k) do {} while (0)
 #endif
 
 struct Veh {
@@ -922,6 +959,199 @@ MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// sweep kernel of the split interior-point step: ONE LANE PER ENV
+// ------------------------------------------------------------------------------------------------
+// The reference steps an env's vehicles front to back and each MDPLCVehicle.step solves its own QP after the vehicles
+// ahead of it have moved (road.py:286, safe_controller.py:106-185, decentral_layer.py:126-135): per env the QPs of a
+// sub-step form a chain, about one of them is ready at a time, and an interior-point solve is ~6 dependent iterations
+// (100 for the 0.4 % that run to cvxopt's iteration cap).  With a lane per VEHICLE (the fused kernels) a wave holds 8 envs
+// and iterates with ~8 of its 64 lanes busy.  Here a lane owns a whole ENV and walks its vehicles in sweep order -- the
+// literal Gauss-Seidel sweep of the reference, no fixed point, no veto passes: classify the others as the ego sees them
+// now (multi_agent_state), build the CBF rows, solve the QP (include/mm_qp.h, resumable: every lane of the wave is at its
+// own iteration of its own QP), evaluate status / veto / flags (shield_post), publish the ego's committed post-state for
+// the egos behind it.  64 envs per wave, every lane busy until its env is through.
+// What the others see of a vehicle lives in the SweepBuf view planes (SW_W*): written pre-step by the phase kernel, replaced
+// by the post-step view when the vehicle commits.  All lanes of a wave read "vehicle o" of their envs together (coalesced);
+// the ego's own fields and the three selected neighbours are gathers.
+// NV: compile-time bound on N (the classification keys live in registers).
+template <int NV, bool MASS>
+__global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int k, double *trace, long long A) {
+  const int ln = threadIdx.x;
+  const long long e = (long long)blockIdx.x * 64 + ln;
+  const int N = sb.N;
+  const double dt = c.dt;
+  // The views of the env's vehicles live in LDS for the whole sweep, one column per lane (= env): every ego reads all of them,
+  // and a global round trip per read is ~2 us for a lone wave.  [field][vehicle][lane]: the lanes of a wave read "vehicle o"
+  // together and a gather "vehicle j(lane)" differs by whole 512-byte rows -- no bank conflicts either way.
+  __shared__ double s_w[6][NV][64];  // SW_WX .. SW_WVX
+  __shared__ int s_pk[NV][64], s_meta[NV][64];
+  enum { PH_SETUP = 0, PH_RUN = 1, PH_FIN = 2, PH_DONE = 3 };
+  int phase = e < c.E ? PH_SETUP : PH_DONE;
+  unsigned long long ord_lo = ~0ull, ord_hi = ~0ull;  // sweep order, one byte per rank (0..7 | 8..15)
+  if (phase != PH_DONE) {
+#pragma unroll
+    for (int o = 0; o < NV; o++) {
+      if (o < N) {
+#pragma unroll
+        for (int f = 0; f < 6; f++) s_w[f][o][ln] = sw_f(sb, f, o, e);
+        s_pk[o][ln] = sw_i(sb, SW_WPK, o, e);
+        s_meta[o][ln] = sw_i(sb, SW_META, o, e);
+        const unsigned long long ob = sb.order[(long long)o * sb.Ep + e];
+        if (o < 8) ord_lo = (ord_lo & ~(0xFFull << (8 * o))) | ob << (8 * o);
+        else ord_hi = (ord_hi & ~(0xFFull << (8 * (o - 8)))) | ob << (8 * (o - 8));
+      } else {
+        s_meta[o][ln] = 0;
+      }
+    }
+  }
+  int r = 0;         // next sweep rank to look at
+  int ego = 0;       // creation index of the vehicle whose QP this lane is solving
+  int ego_meta = 0;
+  bool sing = false, opt = false;
+  double e_v = 0;  // the ego's speed (shield_post and the published view read it again after the QP)
+  // what the ego publishes when it commits: fetched while its QP iterates
+  double p_h1x = 0, p_h1vx = 0, p_ax = 0, p_ay = 0, p_ah = 0, p_ag = 0, p_ac = 0;
+  int p_apk = 0;
+  ShieldStatic ss;
+  ShieldRows rw = {0, 0, 0, 0};
+  MMQpState q;
+  MMQpRes rs = {0, 0, 0, 0, 0, 0};
+  {  // (every field is written before it is read: by the first setup of the lane; zeros keep the compiler's dataflow simple)
+    ss.evx = ss.u0 = ss.g0 = ss.g2 = ss.g4 = ss.g6 = ss.u6 = ss.v_min = ss.v_max = ss.h1 = ss.h2 = 0;
+    ss.px_lon = ss.px_lona = ss.px_lonr = ss.q_lon = ss.q_lona = ss.q_lonr = ss.hls_lona = ss.hls_lonr = ss.base0 = ss.base3 = 0;
+    ss.cadj = ss.can_abort_lc = false;
+    q.a = q.h0 = q.h1 = q.h2 = q.h3 = q.resz0 = q.x0 = q.x2 = q.gap = 0;
+    q.s0 = q.s1 = q.s2 = q.s3 = q.z0 = q.z1 = q.z2 = q.z3 = 0;
+    q.d0 = q.d1 = q.d2 = q.d3 = q.di0 = q.di1 = q.di2 = q.di3 = q.l0 = q.l1 = q.l2 = q.l3 = 1.0;
+    q.ax0 = q.ax2 = 0; q.m4 = 0; q.iters = 0;
+  }
+#ifdef MM_STAMPS
+  unsigned long long _t_last = __builtin_amdgcn_s_memtime(), _t_acc = 0;
+#endif
+  for (int trip = 0;; trip++) {
+    SCOUNT(4);
+    if (trip > (MM_QP_MAXITERS + 3) * (NV + 1)) { atomicOr(c.err, MM_LATCH_INTERNAL); break; }  // cannot happen: every trip advances a QP or the rank
+    // (1) cvxopt's stopping test for the running QPs
+    if (phase == PH_RUN) {
+      const int stop = mm_qp_top(&q, &rs);
+      if (stop || sing) { phase = PH_FIN; opt = stop == 1 && !sing; }
+    }
+    SSTAMP(0);
+    // (2) a QP stopped: everything after solvers.qp returned (cbf.py:134-161, decentral_layer.py:493-518 / :721-764), then
+    //     Vehicle.step commits and the egos behind see this vehicle's post-step state
+    if (__any(phase == PH_FIN)) {
+      if (phase == PH_FIN) {
+        Veh v;
+        v.v = e_v; v.flags = (ego_meta >> 8) & 255; v.hl = (ego_meta >> 16) & 255;  // (all shield_post reads of the vehicle)
+        const ShieldOut so = shield_post<MASS>(c, v, ss, rw, q.x0, opt, true);
+        if (so.bounds) atomicOr(c.err, MM_LATCH_QP_BOUNDS);
+        const bool needB = (ego_meta & 4) != 0, use_B = so.veto && needB;
+        if (use_B) {  // (rare: the LC-veto candidate is fetched on demand)
+          p_ax = sw_f(sb, SW_BX, ego, e); p_ay = sw_f(sb, SW_BY, ego, e); p_ah = sw_f(sb, SW_BH, ego, e);
+          p_ag = sw_f(sb, SW_BGVX, ego, e); p_ac = sw_f(sb, SW_BCPSI, ego, e); p_apk = sw_i(sb, SW_BPK, ego, e);
+        }
+        double nv = e_v + so.acc * dt;
+        nv = nv > 0 ? nv : 0;
+        s_w[SW_WX][ego][ln] = p_ax; s_w[SW_WY][ego][ln] = p_ay; s_w[SW_WH][ego][ln] = p_ah; s_pk[ego][ln] = p_apk;
+        s_w[SW_WHX][ego][ln] = p_h1x;
+        s_w[SW_WGU][ego][ln] = slot_gu<MASS>(p_h1vx, MASS ? so.acc : kCbfAccLo, p_ag, dt);
+        s_w[SW_WVX][ego][ln] = nv * p_ac;
+        sw_f(sb, SW_ACC, ego, e) = so.acc;
+        sw_i(sb, SW_RES, ego, e) = 1 | (so.veto ? 2 : 0) | (use_B ? 4 : 0) | (so.flags & 255) << 8;
+        if (trace) {
+          double *t = trace + (long long)k * MM_T_COUNT * A + e * N + ego;
+          trace_status(t, A, so);
+          t[MM_T_QP_ROWS * A] = so.qt.rows; t[MM_T_QP_A * A] = so.qt.a;
+          t[MM_T_QP_H0 * A] = so.qt.h0; t[MM_T_QP_H1 * A] = so.qt.h1; t[MM_T_QP_H2 * A] = so.qt.h2;
+          t[MM_T_QP_H3 * A] = so.qt.h3; t[MM_T_QP_D * A] = so.qt.d; t[MM_T_LC_MARGIN * A] = so.qt.margin;
+        }
+        r += 1;
+        phase = PH_SETUP;
+      }
+    }
+    SSTAMP(1);
+    // (3) next ego of the env: multi_agent_state (decentral_layer.py:85-257) on the views as they stand, the CBF rows, the
+    //     initial point of its QP
+    if (__any(phase == PH_SETUP)) {
+      SCOUNT(5);
+      if (phase == PH_SETUP) {
+        ego = 0xFF;
+        for (; r < N; r++) {  // the next vehicle in sweep order that runs a shield (gate: safe_controller.py:232-239)
+          const int o = (int)(((r < 8 ? ord_lo : ord_hi) >> (8 * (r & 7))) & 255);
+          if (o == 0xFF) { r = N; break; }
+          ego_meta = s_meta[o][ln];
+          if (ego_meta & 2) { ego = o; break; }
+        }
+        if (ego == 0xFF) {
+          phase = PH_DONE;
+        } else {
+          // the ego's own inputs and what it will publish: global loads issued now, the classification below runs on LDS meanwhile
+          e_v = sw_f(sb, SW_V, ego, e);
+          const double e_gvx = sw_f(sb, SW_GVX, ego, e), e_acc = sw_f(sb, SW_ACCN, ego, e);
+          const double cpsi = sw_f(sb, SW_CPSI, ego, e);
+          p_h1x = sw_f(sb, SW_H1X, ego, e); p_h1vx = sw_f(sb, SW_H1VX, ego, e);
+          p_ax = sw_f(sb, SW_AX, ego, e); p_ay = sw_f(sb, SW_AY, ego, e); p_ah = sw_f(sb, SW_AH, ego, e);
+          p_ag = sw_f(sb, SW_AGVX, ego, e); p_ac = sw_f(sb, SW_ACPSI, ego, e); p_apk = sw_i(sb, SW_APK, ego, e);
+          const double ex = s_w[SW_WX][ego][ln], ey = s_w[SW_WY][ego][ln];
+          const int epk = s_pk[ego][ln];
+          double key[NV];
+          double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
+          int j_ol = -1, j_oa = -1, j_oar = -1;
+          bool cadj = false;
+#pragma unroll
+          for (int o = 0; o < NV; o++) {
+            const bool other = (s_meta[o][ln] & 1) != 0 && o != ego;  // (o >= N: meta 0)
+            const Rel rl = relate(ex, ey, epk, other, s_w[SW_WX][o][ln], s_w[SW_WY][o][ln], s_w[SW_WH][o][ln], s_pk[o][ln]);
+            key[o] = rl.key;
+            // first in sorted order per class: smaller key, ties by creation index (ascending o: a strict < keeps the earlier one)
+            if (rl.cls == 1 && rl.key < k_ol) { k_ol = rl.key; j_ol = o; }
+            if (rl.cls == 2 && rl.key < k_oa) { k_oa = rl.key; j_oa = o; cadj = rl.cflag; }
+            if (rl.cls == 3 && rl.key < k_oar) { k_oar = rl.key; j_oar = o; }
+          }
+          // count = 5 of close_vehicles_to: a slot exists only if its vehicle is among the 5 nearest
+          int pos_ol = 0, pos_oa = 0, pos_oar = 0;
+#pragma unroll
+          for (int o = 0; o < NV; o++) {
+            pos_ol += (key[o] < k_ol || (key[o] == k_ol && o < j_ol)) ? 1 : 0;
+            pos_oa += (key[o] < k_oa || (key[o] == k_oa && o < j_oa)) ? 1 : 0;
+            pos_oar += (key[o] < k_oar || (key[o] == k_oar && o < j_oar)) ? 1 : 0;
+          }
+          Neigh nb;
+          nb.has_ol = j_ol >= 0 && pos_ol < 5; nb.has_oa = j_oa >= 0 && pos_oa < 5; nb.has_oar = j_oar >= 0 && pos_oar < 5;
+          nb.constrain_adj = MASS && nb.has_oa && cadj;
+          const int s_ol = nb.has_ol ? j_ol : 0, s_oa = nb.has_oa ? j_oa : 0, s_oar = nb.has_oar ? j_oar : 0;
+          nb.ol_x = s_w[SW_WHX][s_ol][ln]; nb.ol_gu = s_w[SW_WGU][s_ol][ln];
+          nb.oa_x = s_w[SW_WHX][s_oa][ln]; nb.oa_gu = s_w[SW_WGU][s_oa][ln];
+          nb.oar_x = s_w[SW_WX][s_oar][ln]; nb.oar_vx = s_w[SW_WVX][s_oar][ln];
+          nb.ol_vx = nb.oa_vx = nb.ol_acc = nb.ol_g = nb.oa_acc = nb.oa_g = 0;  // folded into ol_gu / oa_gu
+          obstacle_override<MASS>(nb, ex, ey);
+          Veh v;
+          v.x = ex; v.v = e_v; v.gvx = e_gvx; v.act_acc = e_acc;  // (all shield_static reads of the vehicle)
+          ss = shield_static<MASS>(c, v, cpsi, epk, nb);
+          rw = shield_rows<true>(c, ss, nb);
+          sing = false;
+          // (a singular initial KKT system -- NaN input -- makes cvxopt raise: iterate NaN, "unknown")
+          int stop = mm_qp_start(&q, ss.g0, rw.h0, ss.h1, ss.h2, rw.h3, ss.cadj ? 4 : 3) != 0 ? 0 : 2;
+          if (!stop) stop = mm_qp_top(&q, &rs);
+          phase = stop == 0 ? PH_RUN : PH_FIN;  // (stopped at the initial point: posted in the next trip)
+          opt = stop == 1;
+        }
+      }
+    }
+    SSTAMP(2);
+    // (4) one interior-point iteration of every running QP
+    if (!__any(phase != PH_DONE)) break;
+    if (__any(phase == PH_RUN)) {
+      if (phase == PH_RUN) sing = mm_qp_bottom(&q, &rs) == 0;  // singular KKT matrix: the iterate stands, status "unknown"
+    }
+    SSTAMP(3);
+  }
+#ifdef MM_STAMPS
+  if ((threadIdx.x & 63) < 8 && blockIdx.x < 4096) g_stamps_s[blockIdx.x * 8 + (threadIdx.x & 63)] += _t_acc;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // the fused step kernel
 // ------------------------------------------------------------------------------------------------
 #ifndef MM_MIN_WAVES
@@ -935,6 +1165,9 @@ MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
 #ifndef MM_IPM_WAVES
 #define MM_IPM_WAVES 2
 #endif
+#ifndef MM_SPLIT_WAVES
+#define MM_SPLIT_WAVES 2  // phase form of the step kernel (split interior-point step): 168 registers (3 waves) spill 85 of them
+#endif
 template <int G, int SHIELD, bool MIXED>
 #ifndef MM_GENERAL_NONE_WAVES
 #define MM_GENERAL_NONE_WAVES 3  // mixed-traffic unshielded: 0.49 (2 waves) / 0.445 (3) / 0.51 ms (4)
@@ -944,16 +1177,24 @@ constexpr int step_min_waves(bool ipm = false) { return SHIELD == MM_SHIELD_NONE
 // general (MIXED) instantiations only, which run the literal sweep -- one QP per vehicle per sub-step, as the reference
 // TRACE: the per-sub-step trace planes (MMStepOut.trace, tests / profile export) are a compile-time property: the
 // production instantiation carries neither the stores nor the eight QP-trace registers per lane
-template <int G, int KIND, int SHIELD, bool MIXED, bool IPM = false, bool TRACE = false>
+// SPLIT: the "phase" form of the kernel for the split interior-point step (SweepBuf above).  Launch kb = 0 .. nsub runs the
+// COMMIT half of sub-step kb - 1 (Vehicle.step with the accelerations / vetoes the sweep kernel decided, collisions,
+// terminal test) and then the ACT half of sub-step kb (act, predict candidates A and B, hand the shield's inputs to the
+// sweep kernel) -- or, for kb = nsub, the epilogue (rewards, re-spawn, observation).  The state planes carry the vehicle
+// state from launch to launch; everything else a sub-step keeps in registers / LDS between its two halves goes through
+// the SweepBuf planes.  Same code as the fused form, statement for statement: only the shield sweep between the halves
+// is replaced by the hand-off.
+template <int G, int KIND, int SHIELD, bool MIXED, bool IPM = false, bool TRACE = false, bool SPLIT = false>
 #ifndef MM_STEP_BLOCK
 #define MM_STEP_BLOCK 64  // one wave per workgroup: waves of a 256-thread block drifted ~12 % apart and the block held its LDS until the slowest was done (0.355 -> 0.333 ms)
 #endif
-__global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IPM))) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
-                                                   MMStepOut out, double *metrics) {
+__global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_waves<G, SHIELD, MIXED>(IPM))) void step_kernel(DevCfg c, DevState st, const int32_t *__restrict__ actions,
+                                                   MMStepOut out, double *metrics, SweepBuf sb, int kb) {
   constexpr bool LC = (KIND == MM_ENV_V1);
   constexpr bool SHIELDED = LC && (SHIELD != MM_SHIELD_NONE);
   constexpr bool MASS = (SHIELD == MM_SHIELD_MASS);
   static_assert(!IPM || SHIELDED, "the IPM mode lives in shielded kernels");
+  static_assert(!SPLIT || (IPM && !MIXED), "the split form exists for the CAV-only interior-point kernels");
   // Form of the shield sweep.  Every CAV-only shielded kernel (HSS and MASS) runs the parallel fixed-point form with the
   // literal front-to-back sweep compiled in as fallback (a vehicle moving backwards in x) and as the validation form
   // (debug_flags bit0); the general kernels (HDVs / steer_vel) and the MASS IPM kernels carry the literal sweep ONLY
@@ -999,13 +1240,13 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
   const bool ctrl = v.present && !hdv;  // controlled vehicle (MDPVehicle / MDPLCVehicle)
   int action = (valid && ctrl) ? actions[i] : 1;
   if ((unsigned)action > 4u) {  // self.actions[action]: KeyError in the reference (action.py:194-196) -> latched, acts as IDLE
-    atomicOr(c.err, MM_LATCH_BAD_ACTION);
+    if (!SPLIT || kb == 0) atomicOr(c.err, MM_LATCH_BAD_ACTION);
     action = 1;
   }
   const unsigned present_bits = group_ballot<G>(v.present, gb);
   const unsigned ctrl_bits = group_ballot<G>(ctrl, gb);
   const int n_veh = __popc(present_bits), n_ctrl = __popc(ctrl_bits);
-  steps += 1;  // abstract.py:457
+  if (!SPLIT || kb == 0) steps += 1;  // abstract.py:457 (split form: the first launch of the policy step counts it)
 
   // derived per-vehicle registers the shield keeps current across sub-steps
   double cpsi = 1.0, spsi = 0.0;  // cos / sin of my current heading (every kernel: the bicycle step is built on them)
@@ -1032,7 +1273,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
   // 8..14 (+ the obs staging: 15 slots); the sort keys are a parallel-form temporary
   constexpr bool kRoomy = false;  // (round 1 parked cos(heading) / g.vx in LDS as well: no longer measurable, 0.332 ms either way)
   constexpr int C_CPSI = kColdB + G - 1, C_GVX = C_CPSI + 1;
-  constexpr int kColdN = !SHIELDED ? 15 : (kSerialOnly ? 23 : kColdB + G - 1 + (kRoomy ? 2 : 0));
+  constexpr int kColdN = !SHIELDED ? 15 : ((kSerialOnly || SPLIT) ? 23 : kColdB + G - 1 + (kRoomy ? 2 : 0));
   static_assert(kColdN * MM_STEP_BLOCK * 8 >= (MM_STEP_BLOCK / 64) * 64 * 30 * 4, "the obs staging must fit in the cold slots");
   __shared__ double s_cold[kColdN][MM_STEP_BLOCK];
   const int tid = threadIdx.x;
@@ -1047,14 +1288,20 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
   auto CPSI = [&]() -> double { if constexpr (kRoomy) return s_cold[C_CPSI][tid]; else return cpsi; };
   auto GVX = [&]() -> double { if constexpr (kRoomy) return s_cold[C_GVX][tid]; else return v.gvx; };
   bool env_active = n_ctrl > 0;
+  if constexpr (SPLIT) {
+    if (kb > 0) env_active = e < st.E && sb.envf[e] != 0;
+  }
   STAMP(0);  // load + setup
-  for (int k = 0; k < c.nsub; k++) {
+  // split form: launch kb runs the commit half ("tail") of sub-step kb - 1 and the act half ("head") of sub-step kb
+  const int k_lo = SPLIT ? (kb > 0 ? kb - 1 : 0) : 0, k_hi = SPLIT ? (kb < c.nsub ? kb : c.nsub - 1) : c.nsub - 1;
+  for (int k = k_lo; k <= k_hi; k++) {
+    const bool head = !SPLIT || k == kb, tail = !SPLIT || k != kb;
     const bool live = env_active && v.present;
     QpTrace qt = {0, __builtin_nan(""), __builtin_nan(""), __builtin_nan(""), __builtin_nan(""),
                   __builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
     // Road.act / Road.step order: sorted by x descending, stable (road.py:277,286) -> rank
     int rank = 0;
-    if (SHIELDED || MIXED) {
+    if ((SHIELDED || MIXED) && head) {
       for_partners<G>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         double px = px_d<m, G>(v.x, a);
@@ -1062,13 +1309,13 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
         rank += (pp && (px > v.x || (px == v.x && pidx<m, G>(a) < a))) ? 1 : 0;
       });
     }
-    v.tspeed = s_cold[C_TSPEED][tid];
-    if (live && !hdv) {
+    if (head) v.tspeed = s_cold[C_TSPEED][tid];
+    if (live && !hdv && head) {
       if (time % c.nsub == 0) hl_act<KIND>(v, action);  // action_type.act abstract.py:516-519
     }
     const int tl_pre = v.tlane;  // what an HDV acting before this vehicle still sees
-    if (live && !hdv) controlled_act<!MIXED>(v, -1, sv, st_t);  // road.act road.py:269-278 (general kernels: steering below)
-    s_cold[C_TSPEED][tid] = v.tspeed;
+    if (live && !hdv && head) controlled_act<!MIXED>(v, -1, sv, st_t);  // road.act road.py:269-278 (general kernels: steering below)
+    if (head) s_cold[C_TSPEED][tid] = v.tspeed;
     if constexpr (MIXED) { STAMP(1); }  // (general kernels: "act" = the CAVs' part up to here; slots 3 / 4 / 5 split the HDVs' part)
     if constexpr (MIXED) {
       // ---------------- IDMVehicle.act for the HDVs (behavior.py:74-100) -------------------------
@@ -1174,13 +1421,13 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
       if (live && (!hdv || !v.crashed)) steer_lane(v, sv && !hdv, st_t);
       if (hdv && live) v.gvx += dt;  // IDMVehicle.step: self.timer += dt (behavior.py:102-109)
     }
-    if (live) clip_actions(v, LC && !hdv, st_t);
+    if (live && head) clip_actions(v, LC && !hdv, st_t);
     STAMP(1);  // act
     // predicted post-state for the nominal steering (the only one when nothing vetoes)
     Cand cA;
     memset(&cA, 0, sizeof cA);
     const bool shield_on = SHIELDED && live && !hdv && v.hist_len >= 2;  // gate safe_controller.py:232-239
-    if (live) cA = predict<KIND, SHIELDED, MASS, MIXED>(v, v.act_steer, st_t, spsi, cpsi, dt, sv && !hdv);
+    if (live && head) cA = predict<KIND, SHIELDED, MASS, MIXED>(v, v.act_steer, st_t, spsi, cpsi, dt, sv && !hdv);
     auto park = [&](auto base_c, const Cand &cc, double steer) {  // a candidate's LDS image (shielded kernels only)
       constexpr int base = decltype(base_c)::value;
       if constexpr (SHIELDED) {
@@ -1189,7 +1436,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
         s_cold[base + 6][tid] = cc.gvx; s_cold[base + 7][tid] = cc.spsi;
       }
     };
-    park(std::integral_constant<int, C_A>{}, cA, v.act_steer);
+    if (head) park(std::integral_constant<int, C_A>{}, cA, v.act_steer);
     STAMP(2);  // predict A
     // LC veto re-steers to the CURRENT lane (decentral_layer.py:501-506,739-744); identical to the
     // nominal command unless a lane change / lane hand-over is under way or the car crashed.
@@ -1223,11 +1470,59 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
         return cc;
       }
     };
+    if constexpr (SPLIT) {
+      if (!head && live && valid) {
+        // commit half of sub-step k: what its act half (previous launch) left in the hand-off planes -- the clipped nominal
+        // acceleration and the candidate images -- goes back where the fused form keeps it
+        v.act_acc = sw_f(sb, SW_ACCN, a, e);
+        s_cold[C_A + 0][tid] = sw_f(sb, SW_AX, a, e); s_cold[C_A + 1][tid] = sw_f(sb, SW_AY, a, e); s_cold[C_A + 2][tid] = sw_f(sb, SW_AH, a, e);
+        cold_i(C_A + 3, tid) = sw_i(sb, SW_APK, a, e); s_cold[C_A + 4][tid] = sw_f(sb, SW_ACPSI, a, e); s_cold[C_A + 5][tid] = sw_f(sb, SW_ASTEER, a, e);
+        s_cold[C_A + 6][tid] = sw_f(sb, SW_AGVX, a, e); s_cold[C_A + 7][tid] = sw_f(sb, SW_ASPSI, a, e);
+        if (needB) {
+          s_cold[C_B + 0][tid] = sw_f(sb, SW_BX, a, e); s_cold[C_B + 1][tid] = sw_f(sb, SW_BY, a, e); s_cold[C_B + 2][tid] = sw_f(sb, SW_BH, a, e);
+          cold_i(C_B + 3, tid) = sw_i(sb, SW_BPK, a, e); s_cold[C_B + 4][tid] = sw_f(sb, SW_BCPSI, a, e); s_cold[C_B + 5][tid] = sw_f(sb, SW_BSTEER, a, e);
+          s_cold[C_B + 6][tid] = sw_f(sb, SW_BGVX, a, e); s_cold[C_B + 7][tid] = sw_f(sb, SW_BSPSI, a, e);
+          haveB = true;
+        }
+      }
+    }
     double new_acc = v.act_acc;
     bool use_B = false, veto = false;
     int new_flags = v.flags;
+    if constexpr (SPLIT) {
+      if (head) {
+        // act half of sub-step k: hand the shield's inputs to the sweep kernel (one lane per env there)
+        make_B();  // (eagerly, like the literal sweep: the sweep kernel decides the vetoes)
+        const int n_live = __popc(group_ballot<G>(live, gb));
+        if (valid) {
+          sw_i(sb, SW_META, a, e) = (live ? 1 : 0) | (shield_on ? 2 : 0) | (needB ? 4 : 0) | (v.flags & 255) << 8 | (v.hl & 255) << 16;
+          if (live) {
+            // the pre-step view the literal sweep starts from (serial form below: wx .. wgu)
+            sw_f(sb, SW_WX, a, e) = v.x; sw_f(sb, SW_WY, a, e) = v.y; sw_f(sb, SW_WH, a, e) = v.h; sw_i(sb, SW_WPK, a, e) = pk_self;
+            sw_f(sb, SW_WHX, a, e) = s_cold[C_H2X][tid];
+            sw_f(sb, SW_WGU, a, e) = slot_gu<MASS>(s_cold[C_H2VX][tid], MASS ? s_cold[C_SACC][tid] : kCbfAccLo, v.gvx, dt);
+            sw_f(sb, SW_WVX, a, e) = v.v * cpsi;
+            sw_f(sb, SW_V, a, e) = v.v; sw_f(sb, SW_CPSI, a, e) = cpsi; sw_f(sb, SW_GVX, a, e) = v.gvx; sw_f(sb, SW_ACCN, a, e) = v.act_acc;
+            sw_f(sb, SW_H1X, a, e) = s_cold[C_H1X][tid]; sw_f(sb, SW_H1VX, a, e) = s_cold[C_H1VX][tid];
+            sw_f(sb, SW_AX, a, e) = cA.x; sw_f(sb, SW_AY, a, e) = cA.y; sw_f(sb, SW_AH, a, e) = cA.h; sw_i(sb, SW_APK, a, e) = cA.pk;
+            sw_f(sb, SW_ACPSI, a, e) = cA.cpsi; sw_f(sb, SW_AGVX, a, e) = cA.gvx; sw_f(sb, SW_ASTEER, a, e) = v.act_steer; sw_f(sb, SW_ASPSI, a, e) = cA.spsi;
+            if (needB) {
+              sw_f(sb, SW_BX, a, e) = s_cold[C_B + 0][tid]; sw_f(sb, SW_BY, a, e) = s_cold[C_B + 1][tid]; sw_f(sb, SW_BH, a, e) = s_cold[C_B + 2][tid];
+              sw_i(sb, SW_BPK, a, e) = cold_i(C_B + 3, tid); sw_f(sb, SW_BCPSI, a, e) = s_cold[C_B + 4][tid]; sw_f(sb, SW_BSTEER, a, e) = s_cold[C_B + 5][tid];
+              sw_f(sb, SW_BGVX, a, e) = s_cold[C_B + 6][tid]; sw_f(sb, SW_BSPSI, a, e) = s_cold[C_B + 7][tid];
+            }
+            sb.order[(long long)rank * sb.Ep + e] = (uint8_t)a;  // sweep order: ranks 0 .. n_live - 1 are taken by the live vehicles
+          }
+          if (a >= n_live) sb.order[(long long)a * sb.Ep + e] = 0xFF;
+          if (a == 0) sb.envf[e] = env_active ? 1 : 0;
+        }
+      } else if (shield_on && valid) {
+        const int res = sw_i(sb, SW_RES, a, e);  // what the sweep kernel decided for this vehicle
+        new_acc = sw_f(sb, SW_ACC, a, e); veto = (res & 2) != 0; use_B = (res & 4) != 0; new_flags = (res >> 8) & 255;
+      }
+    }
 
-    if constexpr (SHIELDED) {
+    if constexpr (SHIELDED && !SPLIT) {
      if (__any(shield_on)) {
       // Which form runs is a compile-time property of the instantiation (kSerialOnly, above); debug_flags
       // bit0 forces the literal sweep in the kernels that carry both.
@@ -1607,12 +1902,16 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
      }
     }
     STAMP(6);  // serial fallback (if taken) + sweep exit
-    if (SHIELDED && TRACE && live) {  // QP internals go out now so they need not stay in registers
+    if (SPLIT && SHIELDED && out.trace && live && tail && !shield_on) {  // (the sweep kernel wrote the QP planes of the vehicles it ran)
+      out.trace[(long long)k * MM_T_COUNT * A + i + MM_T_QP_ROWS * A] = 0;
+    }
+    if (!SPLIT && SHIELDED && TRACE && live) {  // QP internals go out now so they need not stay in registers
       double *t = out.trace + (long long)k * MM_T_COUNT * A + i;
       t[MM_T_QP_ROWS * A] = qt.rows; t[MM_T_QP_A * A] = qt.a;
       t[MM_T_QP_H0 * A] = qt.h0; t[MM_T_QP_H1 * A] = qt.h1; t[MM_T_QP_H2 * A] = qt.h2;
       t[MM_T_QP_H3 * A] = qt.h3; t[MM_T_QP_D * A] = qt.d; t[MM_T_LC_MARGIN * A] = qt.margin;
     }
+    if (tail) {  // (split form: the commit half)
     // ---------------- commit Vehicle.step / MDPLCVehicle.step for every vehicle -------------------
     if (live) {
       const Cand cc = chosen(use_B);
@@ -1705,7 +2004,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
     }
     STAMP(8);  // collisions
     if (env_active) time += 1;
-    if (TRACE && live) {
+    if (TRACE && live && (!SPLIT || out.trace)) {  // (the split form is instantiated once: the trace is a run-time choice there)
       double *t = out.trace + (long long)k * MM_T_COUNT * A + i;
       t[MM_T_X * A] = v.x; t[MM_T_Y * A] = v.y; t[MM_T_HEADING * A] = v.h; t[MM_T_SPEED * A] = v.v;
       double steer_tr = v.act_steer;
@@ -1720,9 +2019,22 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (step_min_waves<G, SHIELD, MIXED>(IP
     // _is_terminal (merge_env_v1.py:168-172) breaks the sub-step loop (abstract.py:530)
     const bool term = group_ballot<G>(ctrl && (v.crashed || v.x < 0), gb) != 0 || steps >= c.T;
     if (term) env_active = false;
+    }  // tail
   }
 
   STAMP(9);  // trace + terminal
+  if constexpr (SPLIT) {
+    if (kb < c.nsub) {  // more sub-steps to come: the state planes carry the vehicles to the next launch
+      if (valid && v.present) {
+        v.h1x = s_cold[C_H1X][tid]; v.h1vx = s_cold[C_H1VX][tid]; v.h2x = s_cold[C_H2X][tid]; v.h2vx = s_cold[C_H2VX][tid];
+        v.safe_steer = s_cold[C_SSTEER][tid]; v.safe_acc = s_cold[C_SACC][tid];
+        v.tspeed = s_cold[C_TSPEED][tid];
+        store_veh(st, i, v, false);
+      }
+      if (e < st.E && a == 0) { st.I[MM_E_STEPS * st.E + e] = steps; st.I[MM_E_TIME * st.E + e] = time; }
+      return;
+    }
+  }
   // ---------------- rewards / info (merge_env_v1.py:59-166, abstract.py:469-498) -----------------
   const bool env_ok = n_ctrl > 0;
   const unsigned crashed_bits = group_ballot<G>(ctrl && v.crashed, gb);
@@ -2191,8 +2503,22 @@ struct MMHandle_ {
   // that a condition latched by an un-polled mm_step cannot fail a later, valid mm_shield_qp / mm_shield_actions call (or be
   // consumed by it): [MM_LW_STEP] mm_step -> mm_poll_errors, [MM_LW_QP] mm_shield_qp, [MM_LW_SHIELD] mm_shield_actions
   int *dev_err;
+  // hand-off planes of the split interior-point step (SweepBuf): allocated by mm_create / mm_set_config when the
+  // configuration steps that way (shielded v1, qp_solver = MM_QP_IPM, CAV-only), never inside mm_step
+  SweepBuf sweep;
+  void *sweep_mem;
   char err[256];
 };
+static bool needs_general(const MMHandle_ *h) {  // HDVs can appear, or steer_vel lateral control: the kernels that carry IDM / MOBIL
+  return h->cfg.n_hdv > 0 || (h->cfg.traffic_density > 0 && h->cfg.mixed_traffic != 0) ||
+         (h->cfg.env_kind == MM_ENV_V1 && h->cfg.lateral_control == MM_LATERAL_STEER_VEL);
+}
+// The interior-point mode of a CAV-only shielded batch steps as phase kernels + sweep kernels (SweepBuf above);
+// debug_flags bit2 keeps the fused kernel (validation / A-B timing: same results either way).
+static bool steps_split(const MMHandle_ *h) {
+  return h->cfg.env_kind == MM_ENV_V1 && h->cfg.shield != MM_SHIELD_NONE && h->cfg.qp_solver == MM_QP_IPM && !needs_general(h) &&
+         !(h->cfg.debug_flags & 4);
+}
 
 // waves one step launch starts (launch_step_t rounds the grid up to whole MM_STEP_BLOCK-thread blocks): every one of them
 // stores its 64-byte slot of the metrics partial buffer
@@ -2257,6 +2583,22 @@ static int check_cfg(const MMConfig *c, int N, char *err) {
   return MM_OK;
 }
 
+// device memory of the hand-off planes (idempotent; the caller holds a DeviceGuard)
+static hipError_t ensure_sweep(MMHandle_ *h) {
+  if (h->sweep_mem || !steps_split(h)) return hipSuccess;
+  const uint64_t Ep = ((uint64_t)h->E + 63u) & ~(uint64_t)63u, N = (uint64_t)h->N;
+  const uint64_t bF = align256(Ep * N * 8u * SW_F_COUNT), bI = align256(Ep * N * 4u * SW_I_COUNT), bO = align256(Ep * N), bE = align256(Ep);
+  unsigned char *m = nullptr;
+  hipError_t rc = hipMalloc((void **)&m, bF + bI + bO + bE);
+  if (rc != hipSuccess) return rc;
+  rc = hipMemset(m, 0, bF + bI + bO + bE);
+  if (rc != hipSuccess) { (void)hipFree(m); return rc; }
+  h->sweep_mem = m;
+  h->sweep.F = (double *)m; h->sweep.I = (int *)(m + bF); h->sweep.order = m + bF + bI; h->sweep.envf = m + bF + bI + bO;
+  h->sweep.Ep = (long long)Ep; h->sweep.N = h->N;
+  return hipSuccess;
+}
+
 static thread_local char g_create_err[256] = "null handle";  // why the last mm_create of this thread refused (there is no handle to ask)
 // The host-side entries that touch the runtime outside a stream (allocation, latch poll, drain) must address the handle's
 // device, but the caller's current device is the caller's: it is put back on exit (a two-GPU process polling the env of the
@@ -2298,6 +2640,7 @@ extern "C" int32_t mm_create(const MMConfig *cfg, int32_t E, int32_t N, int32_t 
   free(tmp);
   if (rc == hipSuccess) rc = hipMalloc((void **)&h->dev_err, MM_LW_COUNT * sizeof(int));
   if (rc == hipSuccess) rc = hipMemset(h->dev_err, 0, MM_LW_COUNT * sizeof(int));
+  if (rc == hipSuccess) rc = ensure_sweep(h);
   if (rc != hipSuccess) { if (h->dev_err) (void)hipFree(h->dev_err); free(h); return MM_ERR_DEVICE; }
   *out = h;
   return MM_OK;
@@ -2310,6 +2653,7 @@ extern "C" int32_t mm_destroy(MMHandle h) {
   if (rc == hipSuccess) rc = hipDeviceSynchronize();
   if (h->dev_err) (void)hipFree(h->dev_err);
   if (h->metrics_partial) (void)hipFree(h->metrics_partial);
+  if (h->sweep_mem) (void)hipFree(h->sweep_mem);
   free(h);
   return rc == hipSuccess ? MM_OK : MM_ERR_DEVICE;
 }
@@ -2374,8 +2718,12 @@ extern "C" int32_t mm_poll_errors(MMHandle h, MMStream stream) {
 extern "C" int32_t mm_set_config(MMHandle h, const MMConfig *cfg) {
   if (!h) return MM_ERR_INVALID_ARG;
   int rc = check_cfg(cfg, h->N, h->err);
-  if (rc == MM_OK) h->cfg = *cfg;
-  return rc;
+  if (rc != MM_OK) return rc;
+  h->cfg = *cfg;
+  DeviceGuard dg(h->device);  // (the new configuration may step in the split form: its hand-off planes are allocated here)
+  hipError_t hrc = dg.rc;
+  if (hrc == hipSuccess) hrc = ensure_sweep(h);
+  return hrc == hipSuccess ? MM_OK : hip_fail(h, hrc, "hand-off planes of the split interior-point step");
 }
 extern "C" int32_t mm_set_metrics_buffer(MMHandle h, double *metrics) {
   if (!h) return MM_ERR_INVALID_ARG;
@@ -2475,11 +2823,49 @@ static void launch_step_t(MMHandle h, const int32_t *actions, const MMStepOut *o
                                  : (unsigned)((h->E + 64 / G - 1) / (64 / G));  // rotation layouts: 64 / G whole groups per wave
   if (out->trace)
     hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, MIXED, IPM, true>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dev_cfg(h), dev_state(h),
-                       actions, *out, h->metrics ? h->metrics_partial : nullptr);
+                       actions, *out, h->metrics ? h->metrics_partial : nullptr, h->sweep, 0);
   else
     hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, MIXED, IPM, false>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dev_cfg(h), dev_state(h),
-                       actions, *out, h->metrics ? h->metrics_partial : nullptr);
+                       actions, *out, h->metrics ? h->metrics_partial : nullptr, h->sweep, 0);
 }
+#if MM_TU == 0 || MM_TU == 6
+// The split interior-point step (SweepBuf, sweep_kernel): nsub + 1 phase launches with a sweep launch after each act half.
+// All on the caller's stream: each launch reads what the previous one wrote.
+template <int G, int SHIELD>
+static void launch_split_gs(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+  const long long threads = (long long)h->E * G;
+  const unsigned grid = kPow2<G> ? (unsigned)((threads + MM_STEP_BLOCK - 1) / MM_STEP_BLOCK)
+                                 : (unsigned)((h->E + 64 / G - 1) / (64 / G));
+  const DevCfg dc = dev_cfg(h);
+  const DevState ds = dev_state(h);
+  const unsigned sgrid = (unsigned)((h->E + 63) / 64);
+  constexpr bool MASS = SHIELD == MM_SHIELD_MASS;
+  for (int kb = 0; kb <= dc.nsub; kb++) {
+    hipLaunchKernelGGL((step_kernel<G, MM_ENV_V1, SHIELD, false, true, true, true>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dc, ds, actions,
+                       *out, h->metrics ? h->metrics_partial : nullptr, h->sweep, kb);
+    if (kb == dc.nsub) break;
+    if (h->N <= 4) hipLaunchKernelGGL((sweep_kernel<4, MASS>), dim3(sgrid), dim3(64), 0, s, dc, h->sweep, kb, out->trace, ds.A);
+    else if (h->N <= 8) hipLaunchKernelGGL((sweep_kernel<8, MASS>), dim3(sgrid), dim3(64), 0, s, dc, h->sweep, kb, out->trace, ds.A);
+    else hipLaunchKernelGGL((sweep_kernel<12, MASS>), dim3(sgrid), dim3(64), 0, s, dc, h->sweep, kb, out->trace, ds.A);
+  }
+}
+#if MM_TU == 0
+static
+#endif
+void mm_launch_step_split(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+  const bool mass = h->cfg.shield == MM_SHIELD_MASS;
+  switch (g) {
+#define MM_SPLIT_CASE(GG) case GG: if (mass) launch_split_gs<GG, MM_SHIELD_MASS>(h, actions, out, s); else launch_split_gs<GG, MM_SHIELD_HSS>(h, actions, out, s); break;
+#ifdef MM_ONLY_G
+    MM_SPLIT_CASE(MM_ONLY_G)
+#else
+    MM_SPLIT_CASE(2) MM_SPLIT_CASE(4) MM_SPLIT_CASE(6) MM_SPLIT_CASE(8) MM_SPLIT_CASE(12) MM_SPLIT_CASE(16)
+#endif
+#undef MM_SPLIT_CASE
+    default: break;
+  }
+}
+#endif
 template <int G, bool MIXED>
 static void launch_step_m(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
 #ifdef MM_ONLY_SHIELD  // tuning builds: v1 with one shield
@@ -2498,10 +2884,6 @@ static void launch_step_ipm_gm(MMHandle h, const int32_t *actions, const MMStepO
   if (h->cfg.shield == MM_SHIELD_MASS) launch_step_t<G, MM_ENV_V1, MM_SHIELD_MASS, MIXED, true>(h, actions, out, s);
   else launch_step_t<G, MM_ENV_V1, MM_SHIELD_HSS, MIXED, true>(h, actions, out, s);
 }
-static bool needs_general(const MMHandle h) {  // HDVs can appear, or steer_vel lateral control: the kernels that carry IDM / MOBIL
-  return h->cfg.n_hdv > 0 || (h->cfg.traffic_density > 0 && h->cfg.mixed_traffic != 0) ||
-         (h->cfg.env_kind == MM_ENV_V1 && h->cfg.lateral_control == MM_LATERAL_STEER_VEL);
-}
 template <int G>
 static void launch_step_ipm_g(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   if (needs_general(h)) launch_step_ipm_gm<G, true>(h, actions, out, s);
@@ -2515,6 +2897,7 @@ void mm_launch_step_general(MMHandle h, const int32_t *actions, const MMStepOut 
 void mm_launch_step_ipm(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s);
 void mm_launch_step_lanes(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s);
 void mm_launch_step_lanes_ipm(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s);
+void mm_launch_step_split(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s);
 #endif
 #if MM_TU == 0 || MM_TU == 5
 #if MM_TU == 0
@@ -2545,7 +2928,7 @@ void mm_launch_step_lanes(MMHandle h, int g, const int32_t *actions, const MMSte
 #endif
 }
 #endif
-#if MM_TU == 4 || MM_TU == 5
+#if MM_TU == 4 || MM_TU == 5 || MM_TU == 6
 #elif MM_TU == 2
 void mm_launch_step_general(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   switch (group_size(h->N)) {
@@ -2599,6 +2982,10 @@ extern "C" int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *
     hipError_t rc = hipMemsetAsync(out->trace, 0xFF, (size_t)3 * MM_T_COUNT * h->E * h->N * sizeof(double), s);
     if (rc != hipSuccess) return hip_fail(h, rc, "trace memset");
   }
+  if (steps_split(h)) {  // interior-point mode, CAV-only: phase kernels + sweep kernels (SweepBuf)
+    if (!h->sweep_mem) { snprintf(h->err, sizeof h->err, "mm_step: the hand-off planes of the split interior-point step are missing"); return MM_ERR_DEVICE; }
+    mm_launch_step_split(h, step_group(h), actions, out, s);
+  } else
 #ifdef MM_ONLY_G  // tuning builds: one group size, seconds to compile
   launch_step_g<MM_ONLY_G>(h, actions, out, s);
 #else
@@ -2963,6 +3350,18 @@ extern "C" int32_t mm_policy_act(const float *obs, int64_t n, int32_t n_s, const
 }
 
 #ifdef MM_STAMPS
+extern "C" int32_t mm_debug_read_sweep_stamps(unsigned long long *out8, int32_t reset) {
+  static unsigned long long host[4096 * 8];
+  hipError_t rc = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps_s), sizeof host);
+  for (int k = 0; k < 8; k++) out8[k] = 0;
+  for (int w = 0; w < 4096; w++)
+    for (int k = 0; k < 8; k++) out8[k] += host[w * 8 + k];
+  if (rc == hipSuccess && reset) {
+    memset(host, 0, sizeof host);
+    rc = hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_s), host, sizeof host);
+  }
+  return rc == hipSuccess ? MM_OK : MM_ERR_DEVICE;
+}
 extern "C" int32_t mm_debug_read_stamps(unsigned long long *out16, int32_t reset) {
   static unsigned long long *host = nullptr;
   if (!host) host = (unsigned long long *)malloc(sizeof(unsigned long long) * MM_STAMP_WAVES * 16);
