@@ -71,9 +71,13 @@ enum {
   SW_ACC,                                                        // sweep -> phase kernel: the decided acceleration
   SW_F_COUNT
 };
-enum { SW_WPK, SW_APK, SW_BPK, SW_META, SW_RES, SW_I_COUNT };
+enum { SW_WPK, SW_APK, SW_BPK, SW_META, SW_RES, SW_CLS, SW_I_COUNT };
 // SW_META: bit0 live, bit1 shield_on, bit2 needB, bits 8..15 Vehicle flags, bits 16..23 hl_action
 // SW_RES (written by the sweep for every ego it ran): bit0 ran, bit1 veto, bit2 committed candidate B, bits 8..15 new flags
+// SW_CLS: multi_agent_state's slot selection for this vehicle as ego, evaluated by the phase kernel for all vehicles at once
+//   (leader | front-adjacent << 4 | rear-adjacent << 8 creation indices, bits 12..14 the slot exists, bit 15 constrain_adj)
+//   under the assumption that every vehicle ahead of it in the sweep commits candidate A; the sweep kernel classifies again
+//   itself once a vehicle of the env has committed candidate B
 struct SweepBuf {
   double *F;       // [SW_F_COUNT][N][Ep]
   int *I;          // [SW_I_COUNT][N][Ep]
@@ -974,6 +978,12 @@ MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
 // by the post-step view when the vehicle commits.  All lanes of a wave read "vehicle o" of their envs together (coalesced);
 // the ego's own fields and the three selected neighbours are gathers.
 // NV: compile-time bound on N (the classification keys live in registers).
+#ifndef MM_SWEEP_GATE_T
+#define MM_SWEEP_GATE_T 12
+#endif
+#ifndef MM_SWEEP_GATE_W
+#define MM_SWEEP_GATE_W 2
+#endif
 template <int NV, bool MASS>
 __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int k, double *trace, long long A) {
   const int ln = threadIdx.x;
@@ -984,7 +994,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
   // and a global round trip per read is ~2 us for a lone wave.  [field][vehicle][lane]: the lanes of a wave read "vehicle o"
   // together and a gather "vehicle j(lane)" differs by whole 512-byte rows -- no bank conflicts either way.
   __shared__ double s_w[6][NV][64];  // SW_WX .. SW_WVX
-  __shared__ int s_pk[NV][64], s_meta[NV][64];
+  __shared__ int s_pk[NV][64], s_meta[NV][64], s_cls[NV][64];
   enum { PH_SETUP = 0, PH_RUN = 1, PH_FIN = 2, PH_DONE = 3 };
   int phase = e < c.E ? PH_SETUP : PH_DONE;
   unsigned long long ord_lo = ~0ull, ord_hi = ~0ull;  // sweep order, one byte per rank (0..7 | 8..15)
@@ -996,6 +1006,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
         for (int f = 0; f < 6; f++) s_w[f][o][ln] = sw_f(sb, f, o, e);
         s_pk[o][ln] = sw_i(sb, SW_WPK, o, e);
         s_meta[o][ln] = sw_i(sb, SW_META, o, e);
+        s_cls[o][ln] = sw_i(sb, SW_CLS, o, e);
         const unsigned long long ob = sb.order[(long long)o * sb.Ep + e];
         if (o < 8) ord_lo = (ord_lo & ~(0xFFull << (8 * o))) | ob << (8 * o);
         else ord_hi = (ord_hi & ~(0xFFull << (8 * (o - 8)))) | ob << (8 * (o - 8));
@@ -1008,6 +1019,8 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
   int ego = 0;       // creation index of the vehicle whose QP this lane is solving
   int ego_meta = 0;
   bool sing = false, opt = false;
+  // the phase kernel's slot selection (SW_CLS) holds for an ego as long as every vehicle ahead of it committed candidate A
+  bool dirty = (c.debug_flags & 1) != 0;  // (debug_flags bit0: classify here always -- the validation form of this kernel)
   double e_v = 0;  // the ego's speed (shield_post and the published view read it again after the QP)
   // what the ego publishes when it commits: fetched while its QP iterates
   double p_h1x = 0, p_h1vx = 0, p_ax = 0, p_ay = 0, p_ah = 0, p_ag = 0, p_ac = 0;
@@ -1028,18 +1041,29 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
 #ifdef MM_STAMPS
   unsigned long long _t_last = __builtin_amdgcn_s_memtime(), _t_acc = 0;
 #endif
+  int since = 0;       // trips since lanes were last served (wave-uniform)
+  bool serve = false;
   for (int trip = 0;; trip++) {
     SCOUNT(4);
-    if (trip > (MM_QP_MAXITERS + 3) * (NV + 1)) { atomicOr(c.err, MM_LATCH_INTERNAL); break; }  // cannot happen: every trip advances a QP or the rank
+    if (trip > (MM_QP_MAXITERS + 3 + MM_SWEEP_GATE_W) * (NV + 1)) { atomicOr(c.err, MM_LATCH_INTERNAL); break; }  // cannot happen: every trip advances a QP or the rank, or counts towards a service
     // (1) cvxopt's stopping test for the running QPs
     if (phase == PH_RUN) {
       const int stop = mm_qp_top(&q, &rs);
       if (stop || sing) { phase = PH_FIN; opt = stop == 1 && !sing; }
     }
     SSTAMP(0);
+    // Lanes whose QP stopped (or that have none yet) are SERVED -- (2) post / publish, (3) set up the next ego -- together:
+    // the wave executes those ~1 k instructions whenever one lane needs them, so a lone finisher waits up to
+    // MM_SWEEP_GATE_W trips for company unless MM_SWEEP_GATE_T lanes are waiting or nothing else is running.
+    {
+      const int n_wait = __popcll(__ballot(phase == PH_FIN || phase == PH_SETUP)), n_run = __popcll(__ballot(phase == PH_RUN));
+      since += 1;
+      serve = n_wait > 0 && (n_wait >= MM_SWEEP_GATE_T || n_run == 0 || since >= MM_SWEEP_GATE_W);
+      if (serve) since = 0;
+    }
     // (2) a QP stopped: everything after solvers.qp returned (cbf.py:134-161, decentral_layer.py:493-518 / :721-764), then
     //     Vehicle.step commits and the egos behind see this vehicle's post-step state
-    if (__any(phase == PH_FIN)) {
+    if (serve && __any(phase == PH_FIN)) {
       if (phase == PH_FIN) {
         Veh v;
         v.v = e_v; v.flags = (ego_meta >> 8) & 255; v.hl = (ego_meta >> 16) & 255;  // (all shield_post reads of the vehicle)
@@ -1065,6 +1089,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
           t[MM_T_QP_H0 * A] = so.qt.h0; t[MM_T_QP_H1 * A] = so.qt.h1; t[MM_T_QP_H2 * A] = so.qt.h2;
           t[MM_T_QP_H3 * A] = so.qt.h3; t[MM_T_QP_D * A] = so.qt.d; t[MM_T_LC_MARGIN * A] = so.qt.margin;
         }
+        dirty = dirty || use_B;
         r += 1;
         phase = PH_SETUP;
       }
@@ -1072,7 +1097,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
     SSTAMP(1);
     // (3) next ego of the env: multi_agent_state (decentral_layer.py:85-257) on the views as they stand, the CBF rows, the
     //     initial point of its QP
-    if (__any(phase == PH_SETUP)) {
+    if (serve && __any(phase == PH_SETUP)) {
       SCOUNT(5);
       if (phase == PH_SETUP) {
         ego = 0xFF;
@@ -1094,31 +1119,40 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
           p_ag = sw_f(sb, SW_AGVX, ego, e); p_ac = sw_f(sb, SW_ACPSI, ego, e); p_apk = sw_i(sb, SW_APK, ego, e);
           const double ex = s_w[SW_WX][ego][ln], ey = s_w[SW_WY][ego][ln];
           const int epk = s_pk[ego][ln];
-          double key[NV];
-          double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
-          int j_ol = -1, j_oa = -1, j_oar = -1;
-          bool cadj = false;
-#pragma unroll
-          for (int o = 0; o < NV; o++) {
-            const bool other = (s_meta[o][ln] & 1) != 0 && o != ego;  // (o >= N: meta 0)
-            const Rel rl = relate(ex, ey, epk, other, s_w[SW_WX][o][ln], s_w[SW_WY][o][ln], s_w[SW_WH][o][ln], s_pk[o][ln]);
-            key[o] = rl.key;
-            // first in sorted order per class: smaller key, ties by creation index (ascending o: a strict < keeps the earlier one)
-            if (rl.cls == 1 && rl.key < k_ol) { k_ol = rl.key; j_ol = o; }
-            if (rl.cls == 2 && rl.key < k_oa) { k_oa = rl.key; j_oa = o; cadj = rl.cflag; }
-            if (rl.cls == 3 && rl.key < k_oar) { k_oar = rl.key; j_oar = o; }
-          }
-          // count = 5 of close_vehicles_to: a slot exists only if its vehicle is among the 5 nearest
-          int pos_ol = 0, pos_oa = 0, pos_oar = 0;
-#pragma unroll
-          for (int o = 0; o < NV; o++) {
-            pos_ol += (key[o] < k_ol || (key[o] == k_ol && o < j_ol)) ? 1 : 0;
-            pos_oa += (key[o] < k_oa || (key[o] == k_oa && o < j_oa)) ? 1 : 0;
-            pos_oar += (key[o] < k_oar || (key[o] == k_oar && o < j_oar)) ? 1 : 0;
-          }
+          // slot selection: the phase kernel's (all egos of the batch classified at once, lane per vehicle), or -- once a vehicle
+          // ahead committed candidate B, so that this ego sees a pose the phase kernel did not assume -- classified here
+          const int cw = s_cls[ego][ln];
+          int j_ol = cw & 15, j_oa = (cw >> 4) & 15, j_oar = (cw >> 8) & 15;
           Neigh nb;
-          nb.has_ol = j_ol >= 0 && pos_ol < 5; nb.has_oa = j_oa >= 0 && pos_oa < 5; nb.has_oar = j_oar >= 0 && pos_oar < 5;
-          nb.constrain_adj = MASS && nb.has_oa && cadj;
+          nb.has_ol = (cw >> 12) & 1; nb.has_oa = (cw >> 13) & 1; nb.has_oar = (cw >> 14) & 1; nb.constrain_adj = (cw >> 15) & 1;
+          if (__any(dirty)) {
+            if (dirty) {
+              double key[NV];
+              double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
+              bool cadj = false;
+              j_ol = j_oa = j_oar = -1;
+#pragma unroll
+              for (int o = 0; o < NV; o++) {
+                const bool other = (s_meta[o][ln] & 1) != 0 && o != ego;  // (o >= N: meta 0)
+                const Rel rl = relate(ex, ey, epk, other, s_w[SW_WX][o][ln], s_w[SW_WY][o][ln], s_w[SW_WH][o][ln], s_pk[o][ln]);
+                key[o] = rl.key;
+                // first in sorted order per class: smaller key, ties by creation index (ascending o: a strict < keeps the earlier one)
+                if (rl.cls == 1 && rl.key < k_ol) { k_ol = rl.key; j_ol = o; }
+                if (rl.cls == 2 && rl.key < k_oa) { k_oa = rl.key; j_oa = o; cadj = rl.cflag; }
+                if (rl.cls == 3 && rl.key < k_oar) { k_oar = rl.key; j_oar = o; }
+              }
+              // count = 5 of close_vehicles_to: a slot exists only if its vehicle is among the 5 nearest
+              int pos_ol = 0, pos_oa = 0, pos_oar = 0;
+#pragma unroll
+              for (int o = 0; o < NV; o++) {
+                pos_ol += (key[o] < k_ol || (key[o] == k_ol && o < j_ol)) ? 1 : 0;
+                pos_oa += (key[o] < k_oa || (key[o] == k_oa && o < j_oa)) ? 1 : 0;
+                pos_oar += (key[o] < k_oar || (key[o] == k_oar && o < j_oar)) ? 1 : 0;
+              }
+              nb.has_ol = j_ol >= 0 && pos_ol < 5; nb.has_oa = j_oa >= 0 && pos_oa < 5; nb.has_oar = j_oar >= 0 && pos_oar < 5;
+              nb.constrain_adj = MASS && nb.has_oa && cadj;
+            }
+          }
           const int s_ol = nb.has_ol ? j_ol : 0, s_oa = nb.has_oa ? j_oa : 0, s_oar = nb.has_oar ? j_oar : 0;
           nb.ol_x = s_w[SW_WHX][s_ol][ln]; nb.ol_gu = s_w[SW_WGU][s_ol][ln];
           nb.oa_x = s_w[SW_WHX][s_oa][ln]; nb.oa_gu = s_w[SW_WGU][s_oa][ln];
@@ -1273,7 +1307,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
   // 8..14 (+ the obs staging: 15 slots); the sort keys are a parallel-form temporary
   constexpr bool kRoomy = false;  // (round 1 parked cos(heading) / g.vx in LDS as well: no longer measurable, 0.332 ms either way)
   constexpr int C_CPSI = kColdB + G - 1, C_GVX = C_CPSI + 1;
-  constexpr int kColdN = !SHIELDED ? 15 : ((kSerialOnly || SPLIT) ? 23 : kColdB + G - 1 + (kRoomy ? 2 : 0));
+  constexpr int kColdN = !SHIELDED ? 15 : (kSerialOnly ? 23 : kColdB + G - 1 + (kRoomy ? 2 : 0));
   static_assert(kColdN * MM_STEP_BLOCK * 8 >= (MM_STEP_BLOCK / 64) * 64 * 30 * 4, "the obs staging must fit in the cold slots");
   __shared__ double s_cold[kColdN][MM_STEP_BLOCK];
   const int tid = threadIdx.x;
@@ -1522,11 +1556,13 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
       }
     }
 
-    if constexpr (SHIELDED && !SPLIT) {
-     if (__any(shield_on)) {
+    // (split form: only the classification pass of the parallel form runs, in the act half -- its slot selection is handed
+    // to the sweep kernel, which does everything from the rows on; the rest of this block is dead code there)
+    if constexpr (SHIELDED) {
+     if (__any(shield_on) && (!SPLIT || head)) {
       // Which form runs is a compile-time property of the instantiation (kSerialOnly, above); debug_flags
       // bit0 forces the literal sweep in the kernels that carry both.
-      bool serial = kSerialOnly || (c.debug_flags & 1) != 0;
+      bool serial = !SPLIT && (kSerialOnly || (c.debug_flags & 1) != 0);  // (split form: bit0 makes the sweep kernel classify itself)
       ShieldOut so;
       memset(&so, 0, sizeof so);
       if constexpr (!kSerialOnly) {
@@ -1638,6 +1674,12 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
             nb.has_oar = nb.has_oar && pos_oar < 5;
           }
           nb.constrain_adj = MASS && nb.has_oa && cadj;
+          if constexpr (SPLIT) {
+            if (valid && shield_on)
+              sw_i(sb, SW_CLS, a, e) = (j_ol & 15) | (j_oa & 15) << 4 | (j_oar & 15) << 8 | (nb.has_ol ? 1 << 12 : 0) | (nb.has_oa ? 1 << 13 : 0) |
+                                       (nb.has_oar ? 1 << 14 : 0) | (nb.constrain_adj ? 1 << 15 : 0);
+            break;
+          }
           // gather the chosen neighbours' records from their owners' columns (same wave: program order + a
           // wave-level fence make the parked values visible)
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1768,7 +1810,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
         }
        }
       }
-      if (serial) {
+      if (!SPLIT && serial) {
         // ------------- literal front-to-back sweep (fallback / validation form) -----------------
         make_B();
         use_B = false; veto = false; new_acc = v.act_acc; new_flags = v.flags;
