@@ -269,15 +269,23 @@ MMM_FN int mm_qp_top(const MMQpState *q, MMQpRes *r) {
   rx2 = rx2 + u;
   const int dres_ok = ((0.0 + rx0 * rx0) + rx2 * rx2) <= MM_QP_FEASTOL_SQ;  /* dres = resx / resx0 = sqrt(.) / 1 <= feastol */
   r->rx0 = rx0; r->rx2 = rx2; r->rz0 = rz0; r->rz1 = rz1; r->rz2 = rz2; r->rz3 = rz3;
-  const double resz = sqrt(mm_qp_dot(rz0, rz0, rz1, rz1, rz2, rz2, rz3, rz3, m4));
-  const double pcost = f0, dcost = f0 + mm_qp_dot(q->z0, rz0, q->z1, rz1, q->z2, rz2, q->z3, rz3, m4) - gap;
-  int have_rel = 0;
-  double relgap = 0.0;
-  if (pcost < 0.0) { relgap = gap / -pcost; have_rel = 1; }
-  else if (dcost > 0.0) { relgap = gap / dcost; have_rel = 1; }
-  const double pres = resz / q->resz0;
-  const int met = pres <= MM_QP_FEASTOL && dres_ok && (gap <= MM_QP_ABSTOL || (have_rel && relgap <= MM_QP_RELTOL));
   if (q->iters == MM_QP_MAXITERS) return 2;  /* coneqp: the cap wins over a test met in the same iteration */
+  /* met = pres <= feastol and dres <= feastol and (gap <= abstol or (relgap is not None and relgap <= reltol)), evaluated
+   * cheapest condition first: the dual residual settles last, so most iterations need neither the norm of rz (a square
+   * root), pres, nor the relative gap (two divisions) */
+  int met = 0;
+  if (dres_ok) {
+    const double resz = sqrt(mm_qp_dot(rz0, rz0, rz1, rz1, rz2, rz2, rz3, rz3, m4));
+    const double pres = resz / q->resz0;
+    if (pres <= MM_QP_FEASTOL) {
+      if (gap <= MM_QP_ABSTOL) met = 1;
+      else {
+        const double pcost = f0, dcost = f0 + mm_qp_dot(q->z0, rz0, q->z1, rz1, q->z2, rz2, q->z3, rz3, m4) - gap;
+        if (pcost < 0.0) met = gap / -pcost <= MM_QP_RELTOL;
+        else if (dcost > 0.0) met = gap / dcost <= MM_QP_RELTOL;
+      }
+    }
+  }
 #ifdef MM_QP_CERTIFY
   if (!met && mm_qp_frozen(q, r)) return 3;
 #endif

@@ -115,7 +115,8 @@ def default_env_config(env_id):
 
 
 def qp_solver_id(name):
-    """'exact' (closed-form KKT point, default) | 'ipm' (cvxopt's coneqp iterate, fidelity mode)."""
+    """'ipm' (the iterate cvxopt's coneqp stops at -- the reference's own behaviour, the default of every entry point) |
+    'exact' (the closed-form KKT point: explicit opt-in, outside north_star's 1e-5 of the interior-point iterate)."""
     try:
         return {"exact": QP_EXACT, "ipm": QP_IPM, QP_EXACT: QP_EXACT, QP_IPM: QP_IPM}[name]
     except KeyError:
@@ -123,7 +124,7 @@ def qp_solver_id(name):
 
 
 def make_config(env_id, config, cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0, debug_flags=0,
-                n_hdv=0, qp_solver="exact", draw_counts=False, num_cav=0):
+                n_hdv=0, qp_solver="ipm", draw_counts=False, num_cav=0):
     """env.config dict (+ CBFType.GAMMA_B / CBFType.TAU, run_mappo.py:138-139) -> MMConfig."""
     c = MMConfig()
     c.abi_version = MM_ABI_VERSION

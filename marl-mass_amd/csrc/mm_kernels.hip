@@ -979,10 +979,10 @@ MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
 // the ego's own fields and the three selected neighbours are gathers.
 // NV: compile-time bound on N (the classification keys live in registers).
 #ifndef MM_SWEEP_GATE_T
-#define MM_SWEEP_GATE_T 12
+#define MM_SWEEP_GATE_T 48
 #endif
 #ifndef MM_SWEEP_GATE_W
-#define MM_SWEEP_GATE_W 2
+#define MM_SWEEP_GATE_W 8
 #endif
 template <int NV, bool MASS>
 __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int k, double *trace, long long A) {
@@ -998,10 +998,16 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
   enum { PH_SETUP = 0, PH_RUN = 1, PH_FIN = 2, PH_DONE = 3 };
   int phase = e < c.E ? PH_SETUP : PH_DONE;
   unsigned long long ord_lo = ~0ull, ord_hi = ~0ull;  // sweep order, one byte per rank (0..7 | 8..15)
+  // every vehicle's own shield inputs stay in registers (an ego picks its set by a select chain): a global load at the top
+  // of a setup would stall the lone wave for ~2 us
+  double own_v[NV], own_gvx[NV], own_acc[NV], own_cpsi[NV];
+#pragma unroll
+  for (int o = 0; o < NV; o++) own_v[o] = own_gvx[o] = own_acc[o] = own_cpsi[o] = 0.0;
   if (phase != PH_DONE) {
 #pragma unroll
     for (int o = 0; o < NV; o++) {
       if (o < N) {
+        own_v[o] = sw_f(sb, SW_V, o, e); own_gvx[o] = sw_f(sb, SW_GVX, o, e); own_acc[o] = sw_f(sb, SW_ACCN, o, e); own_cpsi[o] = sw_f(sb, SW_CPSI, o, e);
 #pragma unroll
         for (int f = 0; f < 6; f++) s_w[f][o][ln] = sw_f(sb, f, o, e);
         s_pk[o][ln] = sw_i(sb, SW_WPK, o, e);
@@ -1110,10 +1116,12 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
         if (ego == 0xFF) {
           phase = PH_DONE;
         } else {
-          // the ego's own inputs and what it will publish: global loads issued now, the classification below runs on LDS meanwhile
-          e_v = sw_f(sb, SW_V, ego, e);
-          const double e_gvx = sw_f(sb, SW_GVX, ego, e), e_acc = sw_f(sb, SW_ACCN, ego, e);
-          const double cpsi = sw_f(sb, SW_CPSI, ego, e);
+          // what the ego will publish: global loads issued now, consumed when its QP has stopped
+          double e_gvx = 0, e_acc = 0, cpsi = 1;
+#pragma unroll
+          for (int o = 0; o < NV; o++) {
+            if (o == ego) { e_v = own_v[o]; e_gvx = own_gvx[o]; e_acc = own_acc[o]; cpsi = own_cpsi[o]; }
+          }
           p_h1x = sw_f(sb, SW_H1X, ego, e); p_h1vx = sw_f(sb, SW_H1VX, ego, e);
           p_ax = sw_f(sb, SW_AX, ego, e); p_ay = sw_f(sb, SW_AY, ego, e); p_ah = sw_f(sb, SW_AH, ego, e);
           p_ag = sw_f(sb, SW_AGVX, ego, e); p_ac = sw_f(sb, SW_ACPSI, ego, e); p_apk = sw_i(sb, SW_APK, ego, e);

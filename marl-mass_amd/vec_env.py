@@ -31,7 +31,7 @@ class BatchedMergeEnv(object):
 
     def __init__(self, clib, E, N, env_id="merge-multi-agent-v1", config=None, device="cpu",
                  cbf_eta=0.0, cbf_tau=None, auto_reset=False, obs_f64=False, seed=0, first_env=0,
-                 trace=False, debug_flags=0, n_hdv=0, qp_solver="exact", draw_counts=False, num_cav=0, skip_outputs=()):
+                 trace=False, debug_flags=0, n_hdv=0, qp_solver="ipm", draw_counts=False, num_cav=0, skip_outputs=()):
         self.clib, self.E, self.N = clib, int(E), int(N)
         self.env_id = env_id
         self.device = torch.device(device)
@@ -41,7 +41,7 @@ class BatchedMergeEnv(object):
         self.cbf_eta, self.cbf_tau = cbf_eta, cbf_tau
         self.auto_reset, self.obs_f64, self.seed = auto_reset, obs_f64, seed
         self.debug_flags = debug_flags
-        self.qp_solver = qp_solver  # "exact" (closed-form KKT point) | "ipm" (cvxopt's coneqp iterate, fidelity mode)
+        self.qp_solver = qp_solver  # "ipm" (cvxopt's coneqp iterate: the reference's behaviour, default) | "exact" (closed-form KKT point, opt-in)
         self.n_hdv = int(n_hdv)  # device reset: the last n_hdv vehicles of every env are IDM/MOBIL HDVs
         # draw_counts: every (re)spawn draws its vehicle counts as MergeEnv._num_vehicles does (config["traffic_density"]
         # 1..3, config["mixed_traffic"] / "traffic_type"); N is then the slot capacity of a ragged batch

@@ -48,8 +48,13 @@ def env_kwargs(meta):
     cfg = {"safety_guarantee": meta["shield"], "HEADWAY_TIME": meta["headway_time"],
            "action_masking": bool(meta.get("action_masking", False)), "agent_reward": meta.get("agent_reward", "default"),
            "lateral_control": meta.get("lateral_control", "steer")}
-    return dict(env_id=meta["env_id"], config=cfg, cbf_eta=meta["eta"], cbf_tau=meta["headway_time"],
-                obs_f64=True, trace=True, n_hdv=meta.get("n_hdv", 0), qp_solver="ipm" if is_ipm(meta) else "exact")
+    kw = dict(env_id=meta["env_id"], config=cfg, cbf_eta=meta["eta"], cbf_tau=meta["headway_time"],
+              obs_f64=True, trace=True, n_hdv=meta.get("n_hdv", 0))
+    # the ipm_* tapes (cvxopt's interior-point iterate answered solvers.qp) replay on the product's DEFAULT numerics -- no
+    # qp_solver argument; the tapes recorded with the exact KKT point name that mode
+    if not is_ipm(meta):
+        kw["qp_solver"] = "exact"
+    return kw
 
 
 KNIFE_EDGE = 1e-9  # |LC margin| below this = the reference's own decision is rounding noise

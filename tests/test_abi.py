@@ -123,7 +123,7 @@ def test_skipped_outputs_are_not_written_and_change_nothing_else():
     agents_info / action_mask / crashed.  Everything else -- state, obs, the other outputs -- is what the full call gives."""
     import torch
     import oracle_env
-    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5,
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5,
               seed=5, auto_reset=True)
     full, lean = oracle_env.OracleEnv(32, 8, **kw), oracle_env.OracleEnv(32, 8, skip_outputs=("agents_info", "action_mask", "crashed"), **kw)
     full.reset(); lean.reset()
@@ -158,3 +158,16 @@ def test_deferred_metrics_calls_on_the_cpu_twin():
     c = oracle_env.OracleEnv(4, 4, **kw)
     assert c.clib.lib.mm_defer_metrics(c._h, 1, None) == abi.MM_ERR_INVALID_ARG
     assert c.clib.lib.mm_defer_metrics(c._h, 0, None) == abi.MM_OK and c.clib.lib.mm_flush_metrics(c._h, None) == abi.MM_OK
+
+
+def test_default_numerics_is_the_interior_point_iterate():
+    """One default for every product entry point: the QP mode nobody names is cvxopt's interior-point iterate (the
+    reference's behaviour, inside north_star's 1e-5); the closed-form KKT point is an explicit opt-in."""
+    import oracle_env
+    from marl_mass_amd import compat
+    cfg = abi.default_env_config("merge-multi-agent-v1")
+    assert abi.make_config("merge-multi-agent-v1", dict(cfg, safety_guarantee="cbf-cav")).qp_solver == abi.QP_IPM
+    assert abi.make_config("merge-multi-agent-v1", dict(cfg, safety_guarantee="cbf-cav"), qp_solver="exact").qp_solver == abi.QP_EXACT
+    env = oracle_env.OracleEnv(2, 4, config={"safety_guarantee": "cbf-cav"})
+    assert env.qp_solver == "ipm" and env._cfg.qp_solver == abi.QP_IPM
+    assert compat.CBFType.QP_SOLVER == "ipm"

@@ -19,7 +19,7 @@ def _env(make, E, N, td, mixed, **kw):
     # mixed: False (traffic_type "cav") | True ("mixed") | "av" (one CAV among HDVs, merge_env_v1.py:485-489)
     cfg = {"safety_guarantee": kw.pop("shield", "none"), "HEADWAY_TIME": 0.5, "traffic_density": td,
            "traffic_type": mixed if isinstance(mixed, str) else ("mixed" if mixed else "cav"), "mixed_traffic": bool(mixed)}
-    return make(E, N, env_id="merge-multi-agent-v1", config=cfg, cbf_eta=0.03125, cbf_tau=0.5, draw_counts=True, **kw)
+    return make(E, N, env_id="merge-multi-agent-v1", config=cfg, cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, draw_counts=True, **kw)
 
 
 @pytest.mark.parametrize("td,mixed", [(1, False), (1, True), (2, True), (3, False), (3, True)])

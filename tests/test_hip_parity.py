@@ -96,7 +96,7 @@ def test_standalone_safety_layer(path):
 def test_standalone_safety_layer_bits_vs_oracle():
     """Same entry, random states: HIP == oracle (mode 1) bit for bit, MASS with HDVs."""
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
-              cbf_eta=0.03125, cbf_tau=0.5, seed=31, auto_reset=True, n_hdv=3)
+              cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=31, auto_reset=True, n_hdv=3)
     E, N = 512, 8
     gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
     gpu.reset(); cpu.reset()
@@ -151,7 +151,7 @@ def test_random_rollout_vs_oracle(case):
     lateral = case[9] if len(case) > 9 else "steer"
     kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau, "agent_reward": agent_reward,
                                      "lateral_control": lateral},
-              cbf_eta=eta, cbf_tau=tau,
+              cbf_eta=eta, qp_solver="exact", cbf_tau=tau,
               obs_f64=True, seed=1000, auto_reset=True, n_hdv=n_hdv)
     gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
     og, ag = gpu.reset()
@@ -189,7 +189,7 @@ def test_parallel_sweep_equals_literal_serial_sweep(safety, N):
     """The parallel fixed-point form of the shield sweep (what the CAV-only HSS and MASS kernels run) vs the literal
     front-to-back sweep (debug_flags bit0), LC-heavy action tape: identical bits everywhere."""
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5},
-              cbf_eta=0.03125, cbf_tau=0.5, seed=4242, auto_reset=True, trace=True)
+              cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=4242, auto_reset=True, trace=True)
     E = 2048
     fast, slow = _gpu_env(E, N, **kw), _gpu_env(E, N, debug_flags=1, **kw)
     fast.reset()
@@ -222,7 +222,7 @@ def test_six_and_twelve_lane_groups_equal_the_power_of_two_groups(env_id, safety
     give identical bits everywhere: state, trace, observations, every output, the rollout metrics; batch sizes that leave
     the last wave partly empty, an env alone in its launch, action masking on (v0), mixed traffic, steer_vel."""
     kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5, "lateral_control": lateral},
-              cbf_eta=0.03125 if safety != "none" else 0.0, cbf_tau=0.5, seed=99, auto_reset=True, trace=True, n_hdv=n_hdv)
+              cbf_eta=0.03125 if safety != "none" else 0.0, qp_solver="exact", cbf_tau=0.5, seed=99, auto_reset=True, trace=True, n_hdv=n_hdv)
     lanes, pow2 = _gpu_env(E, N, **kw), _gpu_env(E, N, debug_flags=2, **kw)
     ml, mp = lanes.enable_metrics(), pow2.enable_metrics(deferred=True)
     ol, al = lanes.reset(); op, ap = pow2.reset()
@@ -247,7 +247,7 @@ def test_six_and_twelve_lane_groups_equal_the_power_of_two_groups(env_id, safety
 
 def test_float32_obs_matches_float64():
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
-              cbf_eta=0.03125, cbf_tau=0.5, seed=7)
+              cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=7)
     e32, e64 = _gpu_env(256, 8, **kw), _gpu_env(256, 8, obs_f64=True, **kw)
     o32, _ = e32.reset()
     o64, _ = e64.reset()
@@ -374,7 +374,7 @@ def test_deferred_metrics_match_per_step_folding():
     """mm_defer_metrics: the per-wave partials accumulate across steps and reach the caller's 8 doubles only in
     mm_flush_metrics / mm_poll_errors -- same totals as the per-step fold (sums up to reassociation, min and counts exactly),
     nothing visible before the flush, nothing counted twice by a second flush, and switching deferral off flushes."""
-    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125,
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, qp_solver="exact",
               cbf_tau=0.5, seed=5, auto_reset=True)
     a_env, b_env = _gpu_env(777, 8, **kw), _gpu_env(777, 8, **kw)   # (777 envs: the last wave of a launch is partly empty)
     ma, mb = a_env.enable_metrics(), b_env.enable_metrics(deferred=True)
@@ -410,7 +410,7 @@ def test_full_size_bit_exact_vs_oracle(E, N, density):
     OpenMP oracle: every state bit, obs, reward, done of all 524 288 agents -- and the bench sizes of the 6- / 12-lane
     group layouts: 32 768 x 12, and the reference's traffic_density 1 / 3 with the vehicle counts drawn per episode."""
     cfg = {"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}
-    kw = dict(env_id="merge-multi-agent-v1", config=cfg, cbf_eta=0.03125, cbf_tau=0.5, seed=1000, auto_reset=True)
+    kw = dict(env_id="merge-multi-agent-v1", config=cfg, cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=1000, auto_reset=True)
     if density:
         cfg.update({"traffic_density": density, "traffic_type": "cav", "mixed_traffic": False})
         kw["draw_counts"] = True
@@ -444,7 +444,7 @@ def test_full_size_bit_exact_vs_oracle(E, N, density):
 def test_baseline_configs_bit_exact(name, env_id, safety, E, N, eta, tau):
     """BASELINE.json configs c2..c5 at their own sizes: 30 steps with the bench's action
     distribution, every output of every step equal to the oracle's."""
-    kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau}, cbf_eta=eta, cbf_tau=tau,
+    kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau}, cbf_eta=eta, qp_solver="exact", cbf_tau=tau,
               seed=1000, auto_reset=True)
     oracle_env.library().lib.orc_set_threads(16)
     gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
@@ -476,7 +476,7 @@ def test_soak_three_episodes_bit_exact(safety, n_hdv, lateral, N):
     checked against the oracle every 40 steps and at the end -- ~10 M agent-steps per case, every bit,
     for every group size (G = 2, 4, 8, 16) and both kernel families (CAV-only / general)."""
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5, "lateral_control": lateral},
-              cbf_eta=0.03125, cbf_tau=0.5, seed=77, auto_reset=True, n_hdv=n_hdv)
+              cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=77, auto_reset=True, n_hdv=n_hdv)
     E = 4096
     oracle_env.library().lib.orc_set_threads(16)
     gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
@@ -501,7 +501,7 @@ def test_full_size_properties():
     With the shield on and eta=0.03125, tau=0.5 the reference never crashes under the random tape
     (SURVEY App. B), and sharding the batch must not change any env."""
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
-              cbf_eta=0.03125, cbf_tau=0.5, seed=1000)
+              cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=1000)
     E, N = 65536, 8
     env = _gpu_env(E, N, **kw)
     half = VecMergeEnv(E // 2, N, device="cuda:0", first_env=E // 2, **kw)
@@ -527,7 +527,7 @@ def test_ragged_batch_with_absent_slots(safety, with_hdv):
     12-slot env): 2..8 vehicles per env, optionally a CAV prefix followed by HDVs, host-provided spawn on
     both sides, 40 steps, every bit equal to the oracle's."""
     E, N = 512, 8
-    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125,
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, qp_solver="exact",
               cbf_tau=0.5, seed=5, n_hdv=3 if with_hdv else 0)
     gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
     cpu.reset()  # a valid spawn to carve the ragged batch from
@@ -593,7 +593,7 @@ def _compat_replay(compat, z, meta):
 def test_skipped_outputs_on_gpu():
     """VecMergeEnv(skip_outputs=...): NULL MMStepOut pointers are not written by the step kernel, everything else is
     bit-identical to the full call (what bench.py's headline line requests)."""
-    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5,
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5,
               seed=5, auto_reset=True)
     full, lean = _gpu_env(512, 8, **kw), _gpu_env(512, 8, skip_outputs=("agents_info", "action_mask", "crashed"), **kw)
     full.reset(); lean.reset()

@@ -41,7 +41,7 @@ def test_interact_shapes_and_bookkeeping(reward_type):
     torch.manual_seed(0)
     E, N = 6, 4
     env = oracle_env.OracleEnv(E, N, env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
-                               cbf_eta=0.03125, cbf_tau=0.5, seed=5, auto_reset=True)
+                               cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=5, auto_reset=True)
     actor, critic = ActorNetwork(env.n_s, 128, env.n_a), CriticNetwork(env.n_s, env.n_a, 128)
     g = torch.Generator().manual_seed(1)
     ro = DeviceRollout(env, actor, critic, roll_out_n_steps=110, reward_type=reward_type, generator=g)
@@ -58,7 +58,7 @@ def test_interact_shapes_and_bookkeeping(reward_type):
 def test_interact_on_gpu():
     from marl_mass_amd import VecMergeEnv
     E, N = 4096, 8
-    env = VecMergeEnv(E, N, config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5,
+    env = VecMergeEnv(E, N, config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5,
                       seed=5, auto_reset=True)
     actor = ActorNetwork(env.n_s, 128, env.n_a).cuda()
     critic = CriticNetwork(env.n_s, env.n_a, 128).cuda()
@@ -75,7 +75,7 @@ def test_graph_captured_rollout_equals_eager():
     import time
     from marl_mass_amd import VecMergeEnv
     E, N, T = 8192, 8, 25
-    kw = dict(config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5, seed=9, auto_reset=True)
+    kw = dict(config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=9, auto_reset=True)
     torch.manual_seed(3)
 
     class GreedyActor(ActorNetwork):  # exactly one-hot log-probabilities: sampling has a single outcome
@@ -243,7 +243,7 @@ def test_interact_fused_policy_path_is_reproducible():
     def make(seed):
         torch.manual_seed(0)
         env = oracle_env.OracleEnv(16, 4, env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-avs_cint", "HEADWAY_TIME": 0.5},
-                                   cbf_eta=0.03125, cbf_tau=0.5, seed=3, auto_reset=True)
+                                   cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=3, auto_reset=True)
         ro = DeviceRollout(env, ActorNetwork(30, 128, 5), CriticNetwork(30, 5, 128), roll_out_n_steps=12, sample_seed=seed)
         assert ro.fused_policy
         return ro.interact()
@@ -258,7 +258,7 @@ def test_rollout_checkpoint_resume():
     def make():
         torch.manual_seed(0)
         env = oracle_env.OracleEnv(8, 4, env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
-                                   cbf_eta=0.03125, cbf_tau=0.5, seed=3, auto_reset=True)
+                                   cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=3, auto_reset=True)
         return DeviceRollout(env, ActorNetwork(30, 128, 5), CriticNetwork(30, 5, 128), roll_out_n_steps=7, sample_seed=5)
     a = make()
     a.interact()
@@ -280,7 +280,7 @@ def test_evaluate_leaves_the_training_stream_untouched(greedy):
     def make():
         torch.manual_seed(0)
         env = oracle_env.OracleEnv(4, 4, env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
-                                   cbf_eta=0.03125, cbf_tau=0.5, seed=3, auto_reset=True)
+                                   cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=3, auto_reset=True)
 
         class GreedyActor(ActorNetwork):  # deterministic actions: this leg does not depend on the sampler's counter
             def forward(self, state):
@@ -309,7 +309,7 @@ def test_graph_rollout_survives_evaluate_and_reseed():
     buffer is refreshed in place and the graph is re-captured when a baked-in argument changed (eager twin == graph)."""
     from marl_mass_amd import VecMergeEnv
     E, N, T = 2048, 8, 12
-    kw = dict(config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5, seed=9, auto_reset=True)
+    kw = dict(config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=9, auto_reset=True)
     torch.manual_seed(3)
     actor, critic = ActorNetwork(30, 128, 5).cuda(), CriticNetwork(30, 5, 128).cuda()
     eager = DeviceRollout(VecMergeEnv(E, N, **kw), actor, critic, roll_out_n_steps=T, sample_seed=4)
@@ -347,7 +347,7 @@ def test_evaluate_refuses_an_env_without_the_outputs_it_reads():
 def test_step_writes_requested_outputs_into_caller_slots():
     """step(out={key: tensor}): that step writes those outputs into the caller's tensors (a rollout's rewards[t], dones[t],
     ...) and nowhere else; everything else -- state, the other outputs, later steps -- is what a twin without slots gives."""
-    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125,
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, qp_solver="exact",
               cbf_tau=0.5, seed=4, auto_reset=True)
     a_env, b_env = oracle_env.OracleEnv(6, 4, **kw), oracle_env.OracleEnv(6, 4, **kw)
     a_env.reset(); b_env.reset()

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 E, N, STEPS = 48, 4, 104
 KW = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
-          cbf_eta=0.03125, cbf_tau=0.5, seed=77, auto_reset=True)
+          cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=77, auto_reset=True)
 
 
 def _tape():
@@ -134,7 +134,7 @@ def test_checkpoint_resume_is_bit_identical():
     """state_dict / load_state_dict of an env batch (oracle backend): resume reproduces the continuation."""
     import torch
     import oracle_env
-    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125,
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, qp_solver="exact",
               cbf_tau=0.5, seed=12, auto_reset=True, n_hdv=2)
     env = oracle_env.OracleEnv(32, 6, **kw)
     env.reset()

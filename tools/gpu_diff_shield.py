@@ -6,7 +6,7 @@ import oracle_env
 from marl_mass_amd import VecMergeEnv, _cabi as abi
 oracle_env.set_math_mode(1)
 kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5},
-          cbf_eta=0.03125, cbf_tau=0.5, seed=31, auto_reset=True, n_hdv=3)
+          cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=31, auto_reset=True, n_hdv=3)
 E, N = 512, 8
 gpu, cpu = VecMergeEnv(E, N, device="cuda:0", **kw), oracle_env.OracleEnv(E, N, **kw)
 gpu.reset(); cpu.reset()

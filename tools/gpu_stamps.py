@@ -9,7 +9,7 @@ shield = sys.argv[1] if len(sys.argv) > 1 else "cbf-cav"
 n_hdv = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # mixed traffic: build the stamps library with -DMM_ONLY_MIXED=true
 E, N = int(os.environ.get("MM_STAMPS_E", "65536")), 8   # (MM_STAMPS_E=8192: one wave per SIMD, the latency-bound case)
 metrics_on = not os.environ.get("MM_BENCH_NO_METRICS")
-env = VecMergeEnv(E, N, config={"safety_guarantee": shield, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5, seed=1000, auto_reset=True, n_hdv=n_hdv)
+env = VecMergeEnv(E, N, config={"safety_guarantee": shield, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=1000, auto_reset=True, n_hdv=n_hdv)
 if metrics_on: env.enable_metrics()
 env.reset()
 from marl_mass_amd import _cabi as abi

@@ -5,7 +5,7 @@ sys.path.insert(0, REPO)
 import torch
 from marl_mass_amd import VecMergeEnv, _cabi as abi
 for E in (65536, 16384, 8192):
-    env = VecMergeEnv(E, 8, config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5, seed=1000, auto_reset=True,
+    env = VecMergeEnv(E, 8, config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=1000, auto_reset=True,
                       skip_outputs=("agents_info", "action_mask", "crashed"))
     env.enable_metrics(); env.reset()
     g = torch.Generator(device="cuda:0").manual_seed(123)

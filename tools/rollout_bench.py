@@ -7,7 +7,7 @@ from marl_mass_amd import VecMergeEnv
 from marl_mass_amd.rollout import ActorNetwork, CriticNetwork, DeviceRollout
 
 E, N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 65536, 8, 50
-kw = dict(config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5, seed=9, auto_reset=True)
+kw = dict(config={"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=9, auto_reset=True)
 torch.manual_seed(0)
 actor, critic = ActorNetwork(30, 128, 5).cuda(), CriticNetwork(30, 5, 128).cuda()
 for graph in (False, True):
