@@ -2262,7 +2262,14 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
     const bool spawn = valid && (c.traffic_density > 0 ? a < nc + nh : v.present);
     if (spawn) nm = spawn_vehicle(nv, a, nc, nh, seed, (uint32_t)episode);
     if (c.traffic_density > 0 && valid) {  // ragged batch: the slot's occupancy changes with the episode
-      if (!spawn) { v.present = false; v.kind = 0; }
+      if (!spawn) {
+        if (v.present) {  // the slot empties: its planes read zero from now on (not whichever store happened to be the last one)
+          Veh z;
+          memset(&z, 0, sizeof z);
+          store_veh(st, i, z, true);
+        }
+        v.present = false; v.kind = 0;
+      }
       st.B[MM_B_KIND * A + i] = spawn ? (uint8_t)nv.kind : (uint8_t)0;
     }
     if (spawn) {
@@ -2325,7 +2332,12 @@ __global__ __launch_bounds__(256) void reset_kernel(DevCfg c, DevState st, int m
       episode_counts(c, seed, (uint32_t)episode, nc, nh);
       if (valid) {
         if (a < nc + nh) nm = spawn_vehicle(v, a, nc, nh, seed, (uint32_t)episode);
-        else { memset(&v, 0, sizeof v); v.hl = MM_HL_NONE; }  // unused slot of a ragged batch
+        else {  // unused slot of a ragged batch (a slot that empties reads zero in every plane)
+          const bool was = v.present;
+          memset(&v, 0, sizeof v);
+          if (was) store_veh(st, i, v, true);
+          v.hl = MM_HL_NONE;
+        }
         st.B[MM_B_KIND * st.A + i] = (uint8_t)v.kind;
       }
       n_merge = shfl_i(nm, gb);

@@ -1414,7 +1414,14 @@ static void store_env(struct MMHandle_ *h, int64_t e_idx, const Env *e) {
   int32_t *I = (int32_t *)(h->state + h->lay.env_offset);
   for (int a = 0; a < h->N; a++) {
     int64_t i = base + a;
-    if (a >= e->n) { B[MM_B_KIND * A + i] = 0; continue; }
+    if (a >= e->n) {
+      if (B[MM_B_KIND * A + i] != 0) { /* the slot empties (ragged batch, re-drawn counts): every plane reads zero from now on */
+        for (int k = 0; k < MM_F_COUNT; k++) F[k * A + i] = 0.0;
+        for (int k = 0; k < MM_B_COUNT; k++) B[k * A + i] = 0;
+      }
+      B[MM_B_KIND * A + i] = 0;
+      continue;
+    }
     const Veh *v = &e->v[a];
     F[MM_F_X * A + i] = v->x; F[MM_F_Y * A + i] = v->y; F[MM_F_HEADING * A + i] = v->heading;
     F[MM_F_SPEED * A + i] = v->speed; F[MM_F_TARGET_SPEED * A + i] = v->target_speed;

@@ -311,7 +311,10 @@ def test_shield_qp_rejects_foreign_structure():
 # (last column: with the per-sub-step trace -- the trace-carrying and the production instantiation are different kernels)
 IPM_CASES = [("cbf-cav", 8, 0, 256, 110, True), ("cbf-avs_cint", 4, 0, 256, 110, True), ("cbf-cav", 7, 3, 256, 110, True),
              ("cbf-avs_cint", 11, 0, 64, 60, True), ("cbf-cav", 2, 0, 128, 60, True),
-             ("cbf-cav", 8, 0, 256, 110, False), ("cbf-avs_cint", 8, 0, 128, 60, False), ("cbf-cav", 4, 2, 128, 60, False)]
+             ("cbf-cav", 8, 0, 256, 110, False), ("cbf-avs_cint", 8, 0, 128, 60, False), ("cbf-cav", 4, 2, 128, 60, False),
+             # CAV-only MASS / HSS in the 6- / 12-lane groups (N = 5..6, 9..12) and in 16-lane groups' vehicle counts
+             ("cbf-cav", 6, 0, 130, 60, True), ("cbf-cav", 12, 0, 70, 60, True), ("cbf-cav", 5, 0, 64, 40, False),
+             ("cbf-cav", 9, 0, 64, 40, False), ("cbf-avs_cint", 6, 0, 128, 40, False), ("cbf-avs_cint", 12, 0, 64, 40, True)]
 
 
 @pytest.mark.parametrize("safety,N,n_hdv,E,steps,trace", IPM_CASES, ids=lambda c: str(c))
@@ -336,6 +339,40 @@ def test_random_rollout_ipm_vs_oracle(safety, N, n_hdv, E, steps, trace):
             k = abi.T[plane]
             assert torch.equal(gpu.trace[:, k].cpu().nan_to_num(nan=-7.0), cpu.trace[:, k].nan_to_num(nan=-7.0)), (t, plane)
     gpu.poll_errors(); cpu.poll_errors()  # check_bounds never fired
+
+
+@pytest.mark.parametrize("safety,N,E", [("cbf-cav", 8, 200), ("cbf-avs_cint", 4, 256), ("cbf-cav", 11, 70), ("cbf-cav", 6, 130), ("cbf-avs_cint", 2, 64)])
+def test_split_interior_point_step_equals_the_fused_kernel(safety, N, E):
+    """The interior-point mode of a CAV-only batch steps as phase kernels + the lane-per-env sweep kernel.  Same bits -- state,
+    per-sub-step trace (incl. every QP's rows and iterate), outputs -- as (a) the fused kernel with its wave-wide interior-point
+    loop (debug_flags bit2) and (b) the sweep kernel classifying every ego itself instead of taking the phase kernel's slot
+    selection (debug_flags bit0); LC-heavy action tape so that candidate-B commits (the case that invalidates the phase
+    kernel's selection) occur."""
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5,
+              qp_solver="ipm", seed=515, auto_reset=True, trace=True, obs_f64=True)
+    split, fused, slow = _gpu_env(E, N, **kw), _gpu_env(E, N, debug_flags=4, **kw), _gpu_env(E, N, debug_flags=1, **kw)
+    for env in (split, fused, slow):
+        env.reset()
+    g = torch.Generator().manual_seed(3)
+    p = torch.tensor([0.3, 0.2, 0.3, 0.1, 0.1])
+    committed_b = 0
+    for t in range(70):
+        a = torch.multinomial(p, E * N, True, generator=g).view(E, N).int().cuda()
+        outs = [env.step(a) for env in (split, fused, slow)]
+        for other, name in ((fused, "fused"), (slow, "self-classifying sweep")):
+            assert torch.equal(split.u8, other.u8) and torch.equal(split.env_i32, other.env_i32), (t, name)
+            assert torch.equal(split.f64.nan_to_num(), other.f64.nan_to_num()), (t, name)
+            assert torch.equal(split.trace.nan_to_num(nan=-7.0), other.trace.nan_to_num(nan=-7.0)), (t, name)
+        for o in outs[1:]:
+            assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) and torch.equal(outs[0][2], o[2]), t
+            for k in outs[0][3]:
+                assert torch.equal(outs[0][3][k].nan_to_num(), o[3][k].nan_to_num()), (t, k)
+        # a veto that re-steers: safe steering differs from the nominal command
+        tr = split.trace
+        committed_b += int((tr[:, abi.T["SAFE_STEER"]].nan_to_num() != tr[:, abi.T["ACT_STEER"]].nan_to_num()).sum())
+    assert committed_b > 0, "the tape must exercise candidate-B commits"
+    for env in (split, fused, slow):
+        env.poll_errors()
 
 
 def test_bad_action_is_latched():
@@ -403,14 +440,15 @@ def test_deferred_metrics_match_per_step_folding():
     assert torch.allclose(ma, mb, rtol=1e-12, atol=0) and float(mb[4]) == 123 * 777
 
 
-@pytest.mark.parametrize("E,N,density", [(65536, 8, 0), (32768, 12, 0), (65536, 6, 1), (32768, 11, 3)],
-                         ids=["headline", "12-lane-groups", "density1-6-lane", "density3-12-lane"])
-def test_full_size_bit_exact_vs_oracle(E, N, density):
+@pytest.mark.parametrize("E,N,density,qp,steps", [(65536, 8, 0, "exact", 12), (32768, 12, 0, "exact", 12), (65536, 6, 1, "exact", 12),
+                                                  (32768, 11, 3, "exact", 12), (65536, 8, 0, "ipm", 12), (16384, 11, 3, "ipm", 12)],
+                         ids=["headline", "12-lane-groups", "density1-6-lane", "density3-12-lane", "headline-ipm", "density3-12-lane-ipm"])
+def test_full_size_bit_exact_vs_oracle(E, N, density, qp, steps):
     """BASELINE's headline size (65536 envs x 8 CAVs, MASS, auto-reset) for 12 steps against the
     OpenMP oracle: every state bit, obs, reward, done of all 524 288 agents -- and the bench sizes of the 6- / 12-lane
     group layouts: 32 768 x 12, and the reference's traffic_density 1 / 3 with the vehicle counts drawn per episode."""
     cfg = {"safety_guarantee": "cbf-cav", "HEADWAY_TIME": 0.5}
-    kw = dict(env_id="merge-multi-agent-v1", config=cfg, cbf_eta=0.03125, qp_solver="exact", cbf_tau=0.5, seed=1000, auto_reset=True)
+    kw = dict(env_id="merge-multi-agent-v1", config=cfg, cbf_eta=0.03125, qp_solver=qp, cbf_tau=0.5, seed=1000, auto_reset=True)
     if density:
         cfg.update({"traffic_density": density, "traffic_type": "cav", "mixed_traffic": False})
         kw["draw_counts"] = True
@@ -424,7 +462,7 @@ def test_full_size_bit_exact_vs_oracle(E, N, density):
     cpu.env_i32[abi.EP["STEPS"]] = ph
     g = torch.Generator().manual_seed(9)
     p = torch.tensor([0.1, 0.6, 0.1, 0.1, 0.1])
-    for t in range(12):
+    for t in range(steps):
         a = torch.multinomial(p, E * N, True, generator=g).view(E, N).int()
         og, rg, dg, ig = gpu.step(a.cuda())
         oc, rc, dc, ic = cpu.step(a)
@@ -434,17 +472,22 @@ def test_full_size_bit_exact_vs_oracle(E, N, density):
         for k in ("agents_rewards", "regional_rewards", "min_headway", "average_speed", "crashed"):
             assert torch.equal(ig[k].cpu(), ic[k]), (t, k)
     assert int(gpu.env_i32[abi.EP["EPISODE"]].max()) >= 2, "some envs must have auto-reset"
+    gpu.poll_errors(); cpu.poll_errors()
 
 
-@pytest.mark.parametrize("name,env_id,safety,E,N,eta,tau", [
-    ("c2", "merge-multi-agent-v0", "none", 4096, 4, 0.0, 1.2),
-    ("c3", "merge-multi-agent-v1", "cbf-avs_cint", 4096, 4, 0.03125, 0.5),
-    ("c4", "merge-multi-agent-v1", "cbf-cav", 16384, 8, 0.03125, 0.5),
-    ("c5-per-gpu", "merge-multi-agent-v1", "cbf-cav", 8192, 8, 0.03125, 0.5)])
-def test_baseline_configs_bit_exact(name, env_id, safety, E, N, eta, tau):
-    """BASELINE.json configs c2..c5 at their own sizes: 30 steps with the bench's action
-    distribution, every output of every step equal to the oracle's."""
-    kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau}, cbf_eta=eta, qp_solver="exact", cbf_tau=tau,
+@pytest.mark.parametrize("name,env_id,safety,E,N,eta,tau,qp,steps", [
+    ("c2", "merge-multi-agent-v0", "none", 4096, 4, 0.0, 1.2, "exact", 30),
+    ("c3", "merge-multi-agent-v1", "cbf-avs_cint", 4096, 4, 0.03125, 0.5, "exact", 30),
+    ("c4", "merge-multi-agent-v1", "cbf-cav", 16384, 8, 0.03125, 0.5, "exact", 30),
+    ("c5-per-gpu", "merge-multi-agent-v1", "cbf-cav", 8192, 8, 0.03125, 0.5, "exact", 30),
+    # the same configurations on the default numerics (interior-point QP: the split step of the CAV-only batches)
+    ("c3-ipm", "merge-multi-agent-v1", "cbf-avs_cint", 4096, 4, 0.03125, 0.5, "ipm", 15),
+    ("c4-ipm", "merge-multi-agent-v1", "cbf-cav", 16384, 8, 0.03125, 0.5, "ipm", 12),
+    ("c5-per-gpu-ipm", "merge-multi-agent-v1", "cbf-cav", 8192, 8, 0.03125, 0.5, "ipm", 15)])
+def test_baseline_configs_bit_exact(name, env_id, safety, E, N, eta, tau, qp, steps):
+    """BASELINE.json configs c2..c5 at their own sizes: 30 steps (interior-point mode: 12 - 15) with the bench's
+    action distribution, every output of every step equal to the oracle's."""
+    kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau}, cbf_eta=eta, qp_solver=qp, cbf_tau=tau,
               seed=1000, auto_reset=True)
     oracle_env.library().lib.orc_set_threads(16)
     gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
@@ -455,7 +498,7 @@ def test_baseline_configs_bit_exact(name, env_id, safety, E, N, eta, tau):
     cpu.env_i32[abi.EP["STEPS"]] = ph
     g = torch.Generator().manual_seed(17)
     p = torch.tensor([0.1, 0.6, 0.1, 0.1, 0.1])
-    for t in range(30):
+    for t in range(steps):
         a = torch.multinomial(p, E * N, True, generator=g).view(E, N).int()
         og, rg, dg, ig = gpu.step(a.cuda())
         oc, rc, dc, ic = cpu.step(a)
@@ -463,6 +506,7 @@ def test_baseline_configs_bit_exact(name, env_id, safety, E, N, eta, tau):
         for k in ("agents_rewards", "regional_rewards", "agents_dones", "average_speed", "traffic_speed", "min_headway", "crashed", "action_mask"):
             assert torch.equal(ig[k].cpu(), ic[k]), (name, t, k)
     assert torch.equal(gpu.u8.cpu(), cpu.u8) and torch.equal(gpu.f64.cpu().nan_to_num(), cpu.f64.nan_to_num())
+    gpu.poll_errors(); cpu.poll_errors()
 
 
 @pytest.mark.parametrize("safety,n_hdv,lateral,N", [("cbf-cav", 0, "steer", 8), ("cbf-avs_cint", 0, "steer", 8), ("cbf-cav", 3, "steer", 8),

@@ -12,6 +12,9 @@ oracle_env.set_math_mode(1)
 kw = dict(env_id=env_id, config={"safety_guarantee": safety, "HEADWAY_TIME": tau}, cbf_eta=eta, cbf_tau=tau,
           obs_f64=True, seed=1000, auto_reset=True, trace=True, n_hdv=n_hdv, qp_solver=os.environ.get("MM_QP_SOLVER", "exact"))
 import os
+if os.environ.get("MM_DENSITY"):  # ragged batch: vehicle counts drawn per episode
+    kw["config"].update({"traffic_density": int(os.environ["MM_DENSITY"]), "traffic_type": "cav", "mixed_traffic": False})
+    kw["draw_counts"] = True
 gpu, cpu = VecMergeEnv(E, N, device="cuda:0", debug_flags=int(os.environ.get("MM_DEBUG_FLAGS", "0")), **kw), oracle_env.OracleEnv(E, N, **kw)
 gpu.reset(); cpu.reset()
 g = torch.Generator().manual_seed(123)
