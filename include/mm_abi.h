@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MM_ABI_VERSION 5
+#define MM_ABI_VERSION 6
 #define MM_MAX_AGENTS 16 /* vehicles per env (reference draws 2..11, merge_env_v1.py:180-211) */
 #define MM_N_ACTIONS 5   /* DiscreteMetaAction.ACTIONS_ALL, envs/common/action.py:141-147 */
 #define MM_OBS_ROWS 5    /* KinematicObservation vehicles_count, envs/common/observation.py:132 */
@@ -284,7 +284,9 @@ int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec,
  * is_collaborating, collaborate_adj, the veto's target-lane reset -- come back as status bits).
  * act_steer / act_acc / safe_steer / safe_acc: DEV double[E][N]; status: DEV uint8[E][N]
  * (MM_ST_* bits; 0 = shield gated off as in safe_controller.py:232-239, action returned unchanged);
- * margin: DEV double[E][N] LC margin or NULL.
+ * margin: DEV double[E][N] LC margin or NULL; headway: DEV double[E][N] or NULL -- the value the call's
+ * vehicle.set_min_headway(...) leaves in vehicle.min_headway (decentral_layer.py:466,700 -> safe_controller.py:264-265:
+ * (x_leader - x_ego - LENGTH) / vx_ego), NaN where the shield was gated off.
  */
 #define MM_ST_RAN 1u           /* the CBF ran (safe_status is not None) */
 #define MM_ST_IS_OPTIMAL 2u    /* status["is_optimal"] */
@@ -296,7 +298,7 @@ int32_t mm_shield_qp(MMHandle h, int32_t n, const double *G, const double *hvec,
 #define MM_ST_QP_BOUNDS 128u   /* CBFType.check_bounds (cbf.py:87-96) would have raised ValueError: u_safe[0] is
                                   more than 1e-3 outside [v_min, v_max]; the call returns MM_ERR_QP_BOUNDS */
 int32_t mm_shield_actions(MMHandle h, const double *act_steer, const double *act_acc, double *safe_steer,
-                          double *safe_acc, uint8_t *status, double *margin, MMStream stream);
+                          double *safe_acc, uint8_t *status, double *margin, double *headway, MMStream stream);
 
 /*
  * Errors a launch cannot return synchronously.  mm_step / mm_reset only enqueue work; conditions the

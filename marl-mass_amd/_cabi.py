@@ -7,7 +7,7 @@ shared object is loaded is decided by the caller, never silently.
 import ctypes as C
 import os
 
-MM_ABI_VERSION = 5
+MM_ABI_VERSION = 6
 MM_MAX_AGENTS = 16
 ENV_V0, ENV_V1 = 0, 1
 SHIELD_NONE, SHIELD_HSS, SHIELD_MASS = 0, 1, 2
@@ -210,7 +210,7 @@ class CLib(object):
         lib.mm_last_error.argtypes = [vp]
         lib.mm_math_eval.argtypes = [i32, i32, vp, vp, vp, vp]
         lib.mm_geom_eval.argtypes = [i32, i32, vp, vp, vp]
-        lib.mm_shield_actions.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.mm_shield_actions.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.mm_sample_actions.argtypes = [vp, i64, i32, u64, vp, vp, vp]
         lib.mm_policy_act.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, i32, i32, u64, vp, vp, vp, vp]
         lib.mm_last_error.restype = C.c_char_p

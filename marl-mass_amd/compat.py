@@ -426,9 +426,9 @@ def safety_layer(safety_type, action, vehicle, dt, safe_dist="theadway", **kwarg
     also WRITES to the vehicle (decentral_layer.py:497-506 / :725-752): `is_collaborating`, `is_lc_safe`,
     `collaborate_adj` (MASS) and, when the lane change is vetoed, `target_lane_index = lane_index`; this shim does
     the same on the vehicle's state planes (so the next `env.step` sees them exactly as after the reference call)
-    and also returns the three flags in `status` next to is_optimal / is_safe / is_invariant.  What it does not
-    reproduce: `vehicle.min_headway` (a logging attribute) and the in-place history edit of an HDV twin, which the
-    in-step shield applies itself."""
+    and also returns the three flags in `status` next to is_optimal / is_safe / is_invariant, and sets
+    `vehicle.min_headway` like the call's `vehicle.set_min_headway(...)` (decentral_layer.py:466,700).  What it does not
+    reproduce: the in-place history edit of an HDV twin, which the in-step shield applies itself."""
     if safety_type not in ("hss", "av", "avs", "avs_cint", "mass", "cav"):
         raise ValueError("Undefined safety_type:{0}".format(safety_type))
     if safe_dist != "theadway":
@@ -444,7 +444,7 @@ def safety_layer(safety_type, action, vehicle, dt, safe_dist="theadway", **kwarg
     steer = torch.zeros(1, MAX_VEHICLES, dtype=torch.float64)
     acc = torch.zeros(1, MAX_VEHICLES, dtype=torch.float64)
     steer[0, vehicle.id], acc[0, vehicle.id] = float(action["steering"]), float(action["acceleration"])
-    s_s, s_a, st, _ = b.shield_actions(steer, acc)
+    s_s, s_a, st, _, hw = b.shield_actions(steer, acc)
     bits = int(st[0, vehicle.id])
     safe_action = {"acceleration": float(s_a[0, vehicle.id]), "steering": float(s_s[0, vehicle.id])}
     if not bits & abi.ST_RAN:  # gated off like get_safe_action (safe_controller.py:229-239)
@@ -455,6 +455,7 @@ def safety_layer(safety_type, action, vehicle, dt, safe_dist="theadway", **kwarg
               "is_invariant": float(bool(bits & abi.ST_IS_INVARIANT)), "is_lc_safe": bool(bits & abi.ST_IS_LC_SAFE),
               "is_collaborating": bool(bits & abi.ST_IS_COLLABORATING), "collaborate_adj": bool(bits & abi.ST_COLLABORATE_ADJ)}
     # the call's side effects on the vehicle (see the docstring)
+    vehicle.min_headway = float(hw[0, vehicle.id])  # set_min_headway (safe_controller.py:264-265)
     flags = (abi.FLAG_IS_LC_SAFE if status["is_lc_safe"] else 0) | (abi.FLAG_IS_COLLABORATING if status["is_collaborating"] else 0)
     if want == abi.SHIELD_MASS:
         flags |= abi.FLAG_COLLABORATE_ADJ if status["collaborate_adj"] else 0

@@ -2363,7 +2363,7 @@ template <int G, int SHIELD, bool IPM = false>
 __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, const double *__restrict__ act_steer,
                                                      const double *__restrict__ act_acc, double *__restrict__ safe_steer,
                                                      double *__restrict__ safe_acc, uint8_t *__restrict__ status,
-                                                     double *__restrict__ margin) {
+                                                     double *__restrict__ margin, double *__restrict__ headway) {
   constexpr bool MASS = (SHIELD == MM_SHIELD_MASS);
   const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long e = gtid / G;
@@ -2468,6 +2468,7 @@ __global__ __launch_bounds__(256) void shield_kernel(DevCfg c, DevState st, cons
     safe_steer[i] = ss; safe_acc[i] = sa;
     if (status) status[i] = (uint8_t)stt;
     if (margin) margin[i] = on ? so.qt.margin : __builtin_nan("");
+    if (headway) headway[i] = on ? so.hw_num / so.hw_den : __builtin_nan("");  // vehicle.set_min_headway (decentral_layer.py:466,700)
   }
 }
 
@@ -3067,37 +3068,37 @@ extern "C" int32_t mm_step(MMHandle h, const int32_t *actions, const MMStepOut *
 
 template <int G, bool IPM>
 static void launch_shield_gi(MMHandle h, const double *as, const double *aa, double *ss, double *sa, uint8_t *stt,
-                             double *mg, hipStream_t s) {
+                             double *mg, double *hw, hipStream_t s) {
   const long long threads = (long long)h->E * G;
   const unsigned grid = (unsigned)((threads + 255) / 256);
   const int sh = h->cfg.env_kind == MM_ENV_V1 ? h->cfg.shield : MM_SHIELD_NONE;
   DevCfg dc = dev_cfg(h);
   dc.err = h->dev_err + MM_LW_SHIELD;  // this entry reports synchronously from its own latch word
   if (sh == MM_SHIELD_MASS)
-    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_MASS, IPM>), dim3(grid), dim3(256), 0, s, dc, dev_state(h), as, aa, ss, sa, stt, mg);
+    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_MASS, IPM>), dim3(grid), dim3(256), 0, s, dc, dev_state(h), as, aa, ss, sa, stt, mg, hw);
   else if (sh == MM_SHIELD_HSS)
-    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_HSS, IPM>), dim3(grid), dim3(256), 0, s, dc, dev_state(h), as, aa, ss, sa, stt, mg);
+    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_HSS, IPM>), dim3(grid), dim3(256), 0, s, dc, dev_state(h), as, aa, ss, sa, stt, mg, hw);
   else
-    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_NONE, false>), dim3(grid), dim3(256), 0, s, dc, dev_state(h), as, aa, ss, sa, stt, mg);
+    hipLaunchKernelGGL((shield_kernel<G, MM_SHIELD_NONE, false>), dim3(grid), dim3(256), 0, s, dc, dev_state(h), as, aa, ss, sa, stt, mg, hw);
 }
 template <int G>
 static void launch_shield_g(MMHandle h, const double *as, const double *aa, double *ss, double *sa, uint8_t *stt,
-                            double *mg, hipStream_t s) {
-  if (h->cfg.qp_solver == MM_QP_IPM) launch_shield_gi<G, true>(h, as, aa, ss, sa, stt, mg, s);
-  else launch_shield_gi<G, false>(h, as, aa, ss, sa, stt, mg, s);
+                            double *mg, double *hw, hipStream_t s) {
+  if (h->cfg.qp_solver == MM_QP_IPM) launch_shield_gi<G, true>(h, as, aa, ss, sa, stt, mg, hw, s);
+  else launch_shield_gi<G, false>(h, as, aa, ss, sa, stt, mg, hw, s);
 }
 extern "C" int32_t mm_shield_actions(MMHandle h, const double *act_steer, const double *act_acc, double *safe_steer,
-                                     double *safe_acc, uint8_t *status, double *margin, MMStream stream) {
+                                     double *safe_acc, uint8_t *status, double *margin, double *headway, MMStream stream) {
   if (!h || !act_steer || !act_acc || !safe_steer || !safe_acc) return MM_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
 #ifdef MM_ONLY_G
-  launch_shield_g<MM_ONLY_G>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, s);
+  launch_shield_g<MM_ONLY_G>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, headway, s);
 #else
   switch (group_size(h->N)) {
-    case 2: launch_shield_g<2>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, s); break;
-    case 4: launch_shield_g<4>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, s); break;
-    case 8: launch_shield_g<8>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, s); break;
-    default: launch_shield_g<16>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, s); break;
+    case 2: launch_shield_g<2>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, headway, s); break;
+    case 4: launch_shield_g<4>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, headway, s); break;
+    case 8: launch_shield_g<8>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, headway, s); break;
+    default: launch_shield_g<16>(h, act_steer, act_acc, safe_steer, safe_acc, status, margin, headway, s); break;
   }
 #endif
   hipError_t rc = hipGetLastError();

@@ -261,16 +261,17 @@ class BatchedMergeEnv(object):
     def shield_actions(self, act_steer, act_acc):
         """safety_layer(...) (decentral_layer.py:767-817) for every controlled vehicle on the current state,
         each evaluated independently; nothing is stepped.  Inputs / outputs [E, N] float64.
-        Returns (safe_steer, safe_acc, status uint8 bits _cabi.ST_*, lc_margin)."""
+        Returns (safe_steer, safe_acc, status uint8 bits _cabi.ST_*, lc_margin, headway) -- headway: what the call's
+        vehicle.set_min_headway leaves in vehicle.min_headway (decentral_layer.py:466,700), NaN where the shield is gated off."""
         dev = self.device
         a_s = torch.as_tensor(act_steer, dtype=torch.float64, device=dev).reshape(self.E, self.N).contiguous()
         a_a = torch.as_tensor(act_acc, dtype=torch.float64, device=dev).reshape(self.E, self.N).contiguous()
         s_s, s_a = torch.empty_like(a_s), torch.empty_like(a_a)
         st = torch.zeros(self.E, self.N, dtype=torch.uint8, device=dev)
-        mg = torch.empty_like(a_s)
+        mg, hw = torch.empty_like(a_s), torch.empty_like(a_s)
         self.clib.check(self.clib.lib.mm_shield_actions(self._h, _ptr(a_s), _ptr(a_a), _ptr(s_s), _ptr(s_a), _ptr(st),
-                                                        _ptr(mg), self._stream()), self._h)
-        return s_s, s_a, st, mg
+                                                        _ptr(mg), _ptr(hw), self._stream()), self._h)
+        return s_s, s_a, st, mg, hw
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -1681,7 +1681,7 @@ int32_t mm_poll_errors(MMHandle h, MMStream stream) {
 }
 
 int32_t mm_shield_actions(MMHandle h, const double *act_steer, const double *act_acc, double *safe_steer,
-                          double *safe_acc, uint8_t *status, double *margin, MMStream stream) {
+                          double *safe_acc, uint8_t *status, double *margin, double *headway, MMStream stream) {
   (void)stream;
   if (!h || !act_steer || !act_acc || !safe_steer || !safe_acc) return MM_ERR_INVALID_ARG;
   const MMConfig *cfg = &h->cfg;
@@ -1697,6 +1697,7 @@ int32_t mm_shield_actions(MMHandle h, const double *act_steer, const double *act
       safe_steer[i] = act_steer[i]; safe_acc[i] = act_acc[i];
       if (status) status[i] = 0;
       if (margin) margin[i] = NAN;
+      if (headway) headway[i] = NAN;
       if (a >= e.n_ctrl) continue;
       /* gate of get_safe_action (safe_controller.py:229-239) */
       if (cfg->env_kind != MM_ENV_V1 || cfg->shield == MM_SHIELD_NONE || e.v[a].hist_len < 2) continue;
@@ -1717,6 +1718,7 @@ int32_t mm_shield_actions(MMHandle h, const double *act_steer, const double *act
                               ((fl & MM_FLAG_IS_COLLABORATING) ? MM_ST_IS_COLLABORATING : 0) |
                               ((fl & MM_FLAG_COLLABORATE_ADJ) ? MM_ST_COLLABORATE_ADJ : 0));
       if (margin) margin[i] = w.v[a].lc_margin;
+      if (headway) headway[i] = w.v[a].shield_headway;
     }
   }
   return rc_all;

@@ -277,7 +277,7 @@ def check_safety_layer_probes(make_env, path, tol=1e-9):
         _force_state(env, z, meta, int(t), int(cum[t]))
         steer = np.zeros((1, n)); acc = np.zeros((1, n))
         steer[0, :nc], acc[0, :nc] = z["sl_act"][k, :, 0], z["sl_act"][k, :, 1]
-        s_s, s_a, st, mg = env.shield_actions(steer, acc)
+        s_s, s_a, st, mg, _hw = env.shield_actions(steer, acc)
         s_s, s_a, st, mg = s_s[0, :nc].cpu().numpy(), s_a[0, :nc].cpu().numpy(), st[0, :nc].cpu().numpy(), mg[0, :nc].cpu().numpy()
         ref_st = z["sl_status"][k]
         for j in range(nc):

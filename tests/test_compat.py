@@ -240,6 +240,16 @@ def test_safety_layer_shim():
         assert (v.is_lc_safe, v.is_collaborating, v.collaborate_adj) == (st_v["is_lc_safe"], st_v["is_collaborating"], st_v["collaborate_adj"])
         if not st_v["is_lc_safe"]:
             assert v.target_lane_index == v.lane_index
+    # vehicle.set_min_headway of the call (decentral_layer.py:466,700 -> safe_controller.py:264-265): the gap to the leader the
+    # shield selected over the ego's longitudinal speed -- (x_ol - x_e - LENGTH) / vx_e, 181 m ahead when there is no leader
+    xs = sorted(float(w.position[0]) for w in env.controlled_vehicles)
+    for v in env.controlled_vehicles:
+        compat.safety_layer("cav", {"steering": 0.0, "acceleration": 0.0}, v, 1 / 15)
+        hw = v.min_headway
+        vx = max(float(v.speed) * float(np.cos(v.heading)), 1.0)
+        assert np.isfinite(hw) and -5.0 / vx <= hw <= (181.0 - 5.0) / vx + 1e-9
+        if float(v.position[0]) == xs[-1]:  # the front vehicle of the road has the phantom leader
+            assert abs(hw - (181.0 - 5.0) / vx) < 1e-9
     with pytest.raises(ValueError):
         compat.safety_layer("avs_cint", act, veh, 1 / 15)  # env is configured for MASS
     with pytest.raises(ValueError):

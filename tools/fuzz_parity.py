@@ -54,7 +54,7 @@ def draw_case(rng):
     kw = dict(env_id="merge-multi-agent-v1" if v1 else "merge-multi-agent-v0", config=cfg,
               cbf_eta=rng.choice([0.03125, 0.03125, 0.5, 0.1]) if shielded else 0.0, cbf_tau=cfg["HEADWAY_TIME"],
               obs_f64=rng.random() < 0.5, seed=rng.randrange(1, 1 << 30), auto_reset=True, n_hdv=n_hdv,
-              qp_solver="ipm" if (shielded and rng.random() < 0.3) else "exact", trace=rng.random() < 0.3,
+              qp_solver="ipm" if (shielded and rng.random() < float(os.environ.get("MM_FUZZ_IPM_P", "0.3"))) else "exact", trace=rng.random() < 0.3,
               draw_counts=draw_counts)
     # (odd batch sizes: the last wave of the launch is partly empty and an env group may be the only one in its wave)
     E = rng.choice([64, 128, 256, 512, 1, 7, 37, 100, 333]) if kw["qp_solver"] == "exact" else rng.choice([32, 64, 128, 5, 45])
@@ -65,7 +65,7 @@ def draw_case(rng):
 
 
 def run_case(E, N, steps, probs, kw):
-    gpu = VecMergeEnv(E, N, device="cuda:0", **kw)
+    gpu = VecMergeEnv(E, N, device="cuda:0", debug_flags=int(os.environ.get("MM_DEBUG_FLAGS", "0")), **kw)
     cpu = oracle_env.OracleEnv(E, N, **kw)
     og, ag = gpu.reset()
     oc, ac = cpu.reset()
