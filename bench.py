@@ -144,21 +144,27 @@ def ipm_mode_line(args, dev, E, N, cfg, kw, ring, steps=12):
                     "split step (phase kernels + lane-per-env sweep kernel); bit-identical to the oracle's literal restatement of coneqp"}
 
 
-def workload_traffic(E, N, shield, env_id, qp_solver, hdv=0, density=0, pow2=False):
-    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json: one row per profiled workload, written
-    from tools/profile.sh runs of this command); None for a workload that was not profiled."""
+def workload_row(E, N, shield, env_id, qp_solver, hdv=0, density=0, pow2=False, mixed=False):
+    """The row of profiles/traffic.json (one per profiled workload, written from tools/profile.sh runs of this command) that
+    matches this workload, or None for a workload that was not profiled."""
     try:
         tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
         rows = tj["workloads"] if "workloads" in tj else [tj]
         for r in rows:
             w = r["workload"]
             if (w["envs_per_gpu"], w["agents"], w["shield"], w["env_id"], w.get("qp_solver", "exact"), w.get("hdv", 0),
-                    w.get("traffic_density", 0), bool(w.get("pow2_groups", False))) == \
-                    (E, N, shield, env_id, qp_solver, hdv, density, bool(pow2)):
-                return r["bytes_per_launch"]
+                    w.get("traffic_density", 0), bool(w.get("pow2_groups", False)), bool(w.get("mixed_traffic", False))) == \
+                    (E, N, shield, env_id, qp_solver, hdv, density, bool(pow2), bool(mixed)):
+                return r
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def workload_traffic(*a, **k):
+    """HBM bytes per mm_step of that workload from the committed PMC passes (None: not profiled)."""
+    r = workload_row(*a, **k)
+    return None if r is None else r["bytes_per_launch"]
 
 
 def main():
@@ -294,7 +300,7 @@ def main():
         # + the device-side dispatch gap.  Falls back to an eager loop between the same two events.
         kn = max(16, min(steps, 64))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        how = "hipGraph replay of %d launches" % kn
+        how, after = "hipGraph replay of %d launches" % kn, 2 * kn  # (after: mm_steps executed behind the timed region)
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -309,7 +315,7 @@ def main():
                 side.synchronize()
             torch.cuda.current_stream().wait_stream(side)
         except Exception as exc:  # capture refused (e.g. a build without graph support): eager loop
-            how = "eager loop of %d launches (graph capture failed: %s)" % (kn, type(exc).__name__)
+            how, after = "eager loop of %d launches (graph capture failed: %s)" % (kn, type(exc).__name__), kn
             torch.cuda.synchronize()
             e0.record()
             for t in range(kn):
@@ -319,7 +325,7 @@ def main():
         kern_ms = e0.elapsed_time(e1) / kn
         env.flush_metrics()
         env.poll_errors()
-        return elapsed, kern_ms, metrics, env, ring, how, skip
+        return elapsed, kern_ms, metrics, env, ring, (how, after), skip
 
     elapsed, kern_ms, metrics, env, ring, kern_how, skipped = measure(E, first_env, args.steps, args.warmup)
     weak_extra = None
@@ -352,22 +358,21 @@ def main():
         achieved = E * N * b_alg / (kern_ms * 1e-3) / 1e9
         # HBM bytes per launch and VALU instructions per wave from the committed PMC passes of this workload
         # (profiles/traffic.json: one row per profiled workload); null for a workload that was not profiled
-        traffic = None if args.mixed_traffic else workload_traffic(E, N, args.shield, args.env_id, args.qp_solver, args.hdv,
-                                                                   args.traffic_density, args.pow2_groups)
+        wrow = workload_row(E, N, args.shield, args.env_id, args.qp_solver, args.hdv, args.traffic_density, args.pow2_groups,
+                            args.mixed_traffic)
+        traffic = None if wrow is None else wrow["bytes_per_launch"]
         # secondary reading (the kernel is VALU-issue bound): instructions from the committed
         # SQ_INSTS_VALU pass x 4 issue cycles per wave64 instruction, against 1024 SIMDs at the 2.4 GHz peak clock
         valu = None
         try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-            rows = tj["workloads"] if "workloads" in tj else [tj]
-            row = [r for r in rows if r["bytes_per_launch"] == traffic and traffic is not None][0]
+            row = wrow  # (the matched workload's own row: by key, not by byte count)
             sj = json.load(open(os.path.join(REPO, "profiles", row.get("summary", "r01/step_kernel_summary.json"))))
             per_wave = sj["pmc_per_launch"]["SQ_INSTS_VALU"] / sj["pmc_per_launch"]["SQ_WAVES"]
             n_valu = per_wave * (E * 8 // 64 if N <= 8 else E * 16 // 64)
             ach = n_valu * 4 / (kern_ms * 1e-3) / 1e12
             valu = {"bound": "valu-issue", "achieved": ach, "peak": 1024 * 2.4e9 / 1e12, "unit": "T SIMD-cycles/s",
                     "frac": ach / (1024 * 2.4e9 / 1e12), "valu_insts_per_wave": per_wave}
-        except (OSError, KeyError, ValueError, ZeroDivisionError, IndexError):
+        except (OSError, KeyError, ValueError, ZeroDivisionError, IndexError, TypeError):
             pass
         headline = args.shield == "mass" and not args.hdv and args.env_id.endswith("v1") and N == 8 and args.qp_solver == "exact" and not args.traffic_density
         if headline and E_total == 65536:
@@ -418,7 +423,8 @@ def main():
                          "kernel_ms": kern_ms, "alg_bytes_per_agent_step": b_alg,
                          "kernel_ms_note": "measured AFTER the timed region: %s between ONE HIP event pair on the launch stream, / launches "
                                            "= the kernel(s) of one mm_step + the device's dispatch gap (the rollout metrics are deferred: no "
-                                           "flush kernel per step); rocprofv3's kernel-trace average of the same command is under profiles/" % kern_how},
+                                           "flush kernel per step); rocprofv3's kernel-trace average of the same command is under profiles/" % kern_how[0],
+                         "mm_steps_after_timed_region": kern_how[1]},
             "rollout_metrics": {"mean_reward": m[0] / max(m[4], 1), "crashed_episodes": m[1],
                                 "mean_speed": m[2] / max(m[4], 1), "env_steps": m[4],
                                 "mean_merge_percent": m[5] / max(m[6], 1), "episodes": m[6], "min_headway": m[7]},

@@ -2749,6 +2749,8 @@ static void launch_metrics_flush(MMHandle h, hipStream_t s, int reset) {
 extern "C" int32_t mm_flush_metrics(MMHandle h, MMStream stream) {
   if (!h) return MM_ERR_INVALID_ARG;
   if (!h->metrics_deferred || !h->metrics) return MM_OK;  // (not deferred: the caller's buffer is current after every step)
+  DeviceGuard dg(h->device);  // (a multi-GPU process may have another device current: the launch belongs to the handle's)
+  if (dg.rc != hipSuccess) return hip_fail(h, dg.rc, "metrics flush");
   launch_metrics_flush(h, (hipStream_t)stream, 1);
   const hipError_t rc = hipGetLastError();
   return rc == hipSuccess ? MM_OK : hip_fail(h, rc, "metrics flush");
@@ -2760,6 +2762,8 @@ extern "C" int32_t mm_defer_metrics(MMHandle h, int32_t deferred, MMStream strea
     return MM_ERR_INVALID_ARG;
   }
   if ((deferred != 0) == (h->metrics_deferred != 0)) return MM_OK;
+  DeviceGuard dg(h->device);
+  if (dg.rc != hipSuccess) return hip_fail(h, dg.rc, "mm_defer_metrics");
   if (deferred) {  // every row to the identity (reset = 2: nothing is folded), then the step launches accumulate
     const long long waves = step_launch_waves(h);
     hipLaunchKernelGGL(metrics_flush_kernel, dim3((unsigned)((waves + kFlushWaves - 1) / kFlushWaves)), dim3(256), 0,
@@ -2796,6 +2800,15 @@ extern "C" int32_t mm_set_metrics_buffer(MMHandle h, double *metrics) {
     hipError_t rc = dg.rc;
     if (rc == hipSuccess) rc = hipMalloc((void **)&h->metrics_partial, (size_t)waves * 8 * sizeof(double));
     if (rc != hipSuccess) return hip_fail(h, rc, "metrics partial buffer");
+  }
+  if (h->metrics_deferred && h->metrics && metrics != h->metrics) {
+    // the partials were collected for the buffer that is being replaced: fold them into THAT one before the switch (there is
+    // no stream argument here: the null stream, synchronised)
+    DeviceGuard dg(h->device);
+    hipError_t rc = dg.rc;
+    if (rc == hipSuccess) { launch_metrics_flush(h, (hipStream_t)0, 1); rc = hipGetLastError(); }
+    if (rc == hipSuccess) rc = hipStreamSynchronize((hipStream_t)0);
+    if (rc != hipSuccess) return hip_fail(h, rc, "metrics flush before the buffer switch");
   }
   h->metrics = metrics;
   if (!metrics) h->metrics_deferred = 0;  // (no buffer, nothing to defer; what the partials held is dropped)
@@ -2907,9 +2920,15 @@ static void launch_split_gs(MMHandle h, const int32_t *actions, const MMStepOut 
     hipLaunchKernelGGL((step_kernel<G, MM_ENV_V1, SHIELD, false, true, true, true>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dc, ds, actions,
                        *out, h->metrics ? h->metrics_partial : nullptr, h->sweep, kb);
     if (kb == dc.nsub) break;
-    if (h->N <= 4) hipLaunchKernelGGL((sweep_kernel<4, MASS>), dim3(sgrid), dim3(64), 0, s, dc, h->sweep, kb, out->trace, ds.A);
-    else if (h->N <= 8) hipLaunchKernelGGL((sweep_kernel<8, MASS>), dim3(sgrid), dim3(64), 0, s, dc, h->sweep, kb, out->trace, ds.A);
-    else hipLaunchKernelGGL((sweep_kernel<12, MASS>), dim3(sgrid), dim3(64), 0, s, dc, h->sweep, kb, out->trace, ds.A);
+    // One sweep wave per SIMD is the design point (65 536 envs = 1 024 waves = the chip's SIMDs; the kernel is bound by the
+    // latency of a lone wave).  Its LDS footprint would let a CU take five single-wave workgroups -- two of them on one SIMD
+    // at half speed each while another CU holds three -- so every launch asks for dynamic LDS up to 40 KB per workgroup
+    // (160 KB / 4): at most four per CU.
+    auto pad = [](size_t used) { return (unsigned)(used < 40960 ? 40960 - used : 0); };
+    constexpr size_t kPerVeh = 6 * 64 * sizeof(double) + 3 * 64 * sizeof(int);  // s_w + s_pk / s_meta / s_cls of sweep_kernel
+    if (h->N <= 4) hipLaunchKernelGGL((sweep_kernel<4, MASS>), dim3(sgrid), dim3(64), pad(4 * kPerVeh), s, dc, h->sweep, kb, out->trace, ds.A);
+    else if (h->N <= 8) hipLaunchKernelGGL((sweep_kernel<8, MASS>), dim3(sgrid), dim3(64), pad(8 * kPerVeh), s, dc, h->sweep, kb, out->trace, ds.A);
+    else hipLaunchKernelGGL((sweep_kernel<12, MASS>), dim3(sgrid), dim3(64), pad(12 * kPerVeh), s, dc, h->sweep, kb, out->trace, ds.A);
   }
 }
 #if MM_TU == 0

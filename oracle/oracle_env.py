@@ -22,11 +22,9 @@ _LIB = None
 
 
 def build(force=False):
-    src = os.path.join(HERE, "mm_oracle.c")
-    hdr = os.path.join(REPO, "include", "mm_abi.h")
-    stale = (not os.path.exists(LIB)) or (os.path.exists(src) and (
-        os.path.getmtime(LIB) < max(os.path.getmtime(src), os.path.getmtime(hdr))))
-    if force or stale:
+    # make decides what is stale (mm_oracle.c and every header of include/ are its prerequisites); it is not run at all
+    # only where the sources did not travel (a box that received the built library alone)
+    if force or not os.path.exists(LIB) or os.path.exists(os.path.join(HERE, "mm_oracle.c")):
         subprocess.check_call(["make", "-C", HERE, "libmm_oracle.so"], stdout=subprocess.DEVNULL)
     return LIB
 

@@ -360,7 +360,9 @@ def test_step_writes_requested_outputs_into_caller_slots():
         before = b_env.out["regional_rewards"].clone()
         _, ra, da, ia = a_env.step(act)
         _, rb, db, ib = b_env.step(act, out={"regional_rewards": rew[t], "done": don[t]})
-        assert torch.equal(rew[t], ia["regional_rewards"]) and torch.equal(don[t], da) and db is don[t] or torch.equal(db, don[t])
+        assert torch.equal(rew[t], ia["regional_rewards"])  # what went through step(out=...) equals the twin's own outputs
+        assert torch.equal(don[t], da)
+        assert db.data_ptr() == don[t].data_ptr()
         assert ib["regional_rewards"].data_ptr() == rew[t].data_ptr()
         assert torch.equal(b_env.out["regional_rewards"], before), "the env's own buffer was written although a slot was given"
         assert torch.equal(ra, rb) and torch.equal(a_env.state, b_env.state) and torch.equal(ia["agents_rewards"], ib["agents_rewards"])

@@ -36,7 +36,8 @@ for tag in sorted(os.listdir(os.path.join(REPO, "gpurun_out"))):
         "workload": {"envs_per_gpu": c["envs_per_gpu"], "agents": c["agents"], "shield": shield,
                      "env_id": "merge-multi-agent-v1" if "v1" in c["workload"] else "merge-multi-agent-v0",
                      "qp_solver": c["qp_solver"], "hdv": int(c["workload"].split("of which ")[1].split(" HDVs")[0]) if "of which" in c["workload"] else 0,
-                     "traffic_density": c.get("traffic_density", 0), "pow2_groups": bool(c.get("pow2_groups", False))},
+                     "traffic_density": c.get("traffic_density", 0), "pow2_groups": bool(c.get("pow2_groups", False)),
+                     "mixed_traffic": " mixed" in b["metric"]},
         "tag": name, "kernel": d["kernel"].split("(")[0].replace("void ", ""),
         "kernel_avg_ns": d["avg_ns"], "bytes_per_launch": d["hbm_traffic_bytes_per_launch"],
         "fetch_bytes": 2 * pmc["FETCH_SIZE"] * 1024, "write_bytes": pmc["WRITE_SIZE"] * 1024,
@@ -45,7 +46,7 @@ for tag in sorted(os.listdir(os.path.join(REPO, "gpurun_out"))):
         "valu_per_wave": pmc.get("SQ_INSTS_VALU", 0) / max(pmc.get("SQ_WAVES", 1), 1),
         "salu_per_wave": pmc.get("SQ_INSTS_SALU", 0) / max(pmc.get("SQ_WAVES", 1), 1),
         "summary": "%s/%s_summary.json" % (rnd, name)})
-out = {"format": "one row per profiled bench.py workload; bench.py matches (envs_per_gpu, agents, shield, env_id, qp_solver, hdv, traffic_density, pow2_groups) and "
+out = {"format": "one row per profiled bench.py workload; bench.py matches (envs_per_gpu, agents, shield, env_id, qp_solver, hdv, traffic_density, pow2_groups, mixed_traffic) and "
                  "reports bytes_per_launch as roofline.traffic",
        "source": "tools/profile_all.sh -> tools/profile.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the bench.py command "
                  "(KiB units); bytes = 2 x FETCH_SIZE + WRITE_SIZE: the x 2 is the guide's gfx950 correction, confirmed on this path's access "
