@@ -366,6 +366,8 @@ def main():
         valu = None
         try:
             row = wrow  # (the matched workload's own row: by key, not by byte count)
+            if row is None:
+                raise KeyError("workload not profiled")
             sj = json.load(open(os.path.join(REPO, "profiles", row.get("summary", "r01/step_kernel_summary.json"))))
             per_wave = sj["pmc_per_launch"]["SQ_INSTS_VALU"] / sj["pmc_per_launch"]["SQ_WAVES"]
             n_valu = per_wave * (E * 8 // 64 if N <= 8 else E * 16 // 64)
@@ -419,7 +421,8 @@ def main():
                          "traffic_unit": "bytes/launch: rocprofv3 PMC passes of this command, 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction), "
                                          "committed under profiles/ (see profiles/traffic.json: source)",
                          "alg_bytes_per_launch": E * N * b_alg,
-                         "kernel": "step_kernel" if args.qp_solver == "exact" or args.shield == "none" else "4 x step_kernel (phase form) + 3 x sweep_kernel",
+                         "kernel": "step_kernel" if args.qp_solver == "exact" or args.shield == "none" or args.hdv or args.mixed_traffic or E * (8 if N <= 8 else 16) // 64 <= 2048
+                         else "4 x step_kernel (phase form) + 3 x sweep_kernel (CAV-only interior-point step above two fused waves per SIMD)",
                          "kernel_ms": kern_ms, "alg_bytes_per_agent_step": b_alg,
                          "kernel_ms_note": "measured AFTER the timed region: %s between ONE HIP event pair on the launch stream, / launches "
                                            "= the kernel(s) of one mm_step + the device's dispatch gap (the rollout metrics are deferred: no "

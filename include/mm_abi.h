@@ -125,8 +125,11 @@ typedef struct MMConfig {
   int32_t action_masking;       /* config["action_masking"] (abstract.py:200-207,474-481) */
   int32_t auto_reset;           /* 1: step() re-spawns finished envs with the device RNG */
   int32_t obs_f64;              /* 0: obs written as float32, 1: float64 (reference dtype) */
-  int32_t debug_flags;          /* bit0: force the literal serial shield sweep; bit1: step in power-of-two lane groups only (no
-                                   6- / 12-lane layout for N = 5..6 / 9..12).  Validation / A-B timing: same results either way */
+  int32_t debug_flags;          /* bit0: force the literal serial shield sweep (split interior-point step: the sweep kernel classifies
+                                   every ego itself); bit1: step in power-of-two lane groups only (no 6- / 12-lane layout for
+                                   N = 5..6 / 9..12); bit2: interior-point mode in the fused kernel at any batch size; bit3: in the split
+                                   step (phase kernels + lane-per-env sweep kernel) at any batch size -- by default the split step runs
+                                   for CAV-only batches above two fused waves per SIMD.  Validation / A-B timing: same results either way */
   double collision_reward;      /* COLLISION_REWARD 200 */
   double high_speed_reward;     /* HIGH_SPEED_REWARD 1  */
   double headway_cost;          /* HEADWAY_COST 4       */
@@ -144,11 +147,13 @@ typedef struct MMConfig {
                                    MM_LATERAL_STEER (1st-order, default) | MM_LATERAL_STEER_VEL (steering velocity,
                                    KP_STEER 20, STEER_TARGET_RF 0.125); v1 CAVs only, as in the reference */
   int32_t qp_solver;            /* how the shield's QP (cbf.py:128-135, cvxopt.solvers.qp) is solved:
-                                   MM_QP_EXACT  its exact KKT point in closed form (default, production);
-                                   MM_QP_IPM    fidelity mode: the interior-point iterate cvxopt's coneqp algorithm
-                                                stops at (Mehrotra predictor-corrector, NT scaling, abstol 1e-7 /
-                                                reltol 1e-6 / feastol 1e-7, <= 100 iterations), incl. its "unknown"
-                                                status -> is_optimal = 0 (include/mm_qp.h) */
+                                   MM_QP_IPM    the interior-point iterate cvxopt's coneqp algorithm stops at (Mehrotra
+                                                predictor-corrector, NT scaling, abstol 1e-7 / reltol 1e-6 / feastol 1e-7,
+                                                <= 100 iterations) incl. its "unknown" status -> is_optimal = 0
+                                                (include/mm_qp.h): the reference's behaviour and the default of every host
+                                                entry point (_cabi.make_config, VecMergeEnv, MergeEnvCompat);
+                                   MM_QP_EXACT  its exact KKT point in closed form: explicit opt-in -- the true minimiser, up
+                                                to 3e-4 m/s away from the interior-point iterate (outside north_star's 1e-5) */
   int32_t traffic_density;      /* device reset / auto-reset vehicle counts (MergeEnv._num_vehicles, merge_env_v1.py:180-211):
                                    0  fixed: N - n_hdv CAVs + n_hdv HDVs in every episode (BASELINE configs);
                                    1..3  config["traffic_density"]: every episode draws num_CAV and num_HDV uniformly from

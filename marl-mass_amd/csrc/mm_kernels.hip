@@ -2570,17 +2570,26 @@ struct MMHandle_ {
   // configuration steps that way (shielded v1, qp_solver = MM_QP_IPM, CAV-only), never inside mm_step
   SweepBuf sweep;
   void *sweep_mem;
+  int n_simd;  // SIMDs of the handle's device (4 per CU), read at mm_create
   char err[256];
 };
 static bool needs_general(const MMHandle_ *h) {  // HDVs can appear, or steer_vel lateral control: the kernels that carry IDM / MOBIL
   return h->cfg.n_hdv > 0 || (h->cfg.traffic_density > 0 && h->cfg.mixed_traffic != 0) ||
          (h->cfg.env_kind == MM_ENV_V1 && h->cfg.lateral_control == MM_LATERAL_STEER_VEL);
 }
-// The interior-point mode of a CAV-only shielded batch steps as phase kernels + sweep kernels (SweepBuf above);
-// debug_flags bit2 keeps the fused kernel (validation / A-B timing: same results either way).
+// The interior-point mode of a CAV-only shielded batch steps as phase kernels + sweep kernels (SweepBuf above) once the
+// batch is large enough for it.  The split step takes as long as its slowest env needs for its QP chain, almost independent of
+// the batch (one lane per env, one wave per SIMD up to 65 536 envs); the fused kernel iterates with ~8 of 64 lanes busy but a
+// small batch leaves the chip's other lanes idle anyway.  Measured at N = 8 MASS (ms per step, fused / split): 8 192 envs
+// 1.12 / 1.45, 16 384 envs 1.46 / 1.53, 32 768 envs 2.49 / 1.72, 65 536 envs 4.4 / 1.99; 4 096 x 4 HSS 0.30 / 0.61.  Crossover =
+// more than two fused waves per SIMD.  debug_flags bit2 keeps the fused kernel, bit3 forces the split step at any size
+// (validation / A-B timing: same results either way).
 static bool steps_split(const MMHandle_ *h) {
-  return h->cfg.env_kind == MM_ENV_V1 && h->cfg.shield != MM_SHIELD_NONE && h->cfg.qp_solver == MM_QP_IPM && !needs_general(h) &&
-         !(h->cfg.debug_flags & 4);
+  if (!(h->cfg.env_kind == MM_ENV_V1 && h->cfg.shield != MM_SHIELD_NONE && h->cfg.qp_solver == MM_QP_IPM && !needs_general(h))) return false;
+  if (h->cfg.debug_flags & 4) return false;
+  if (h->cfg.debug_flags & 8) return true;
+  const int g = h->N <= 2 ? 2 : (h->N <= 4 ? 4 : (h->N <= 8 ? 8 : 16));
+  return (long long)h->E * g / 64 > 2ll * (h->n_simd > 0 ? h->n_simd : 1024);
 }
 
 // waves one step launch starts (launch_step_t rounds the grid up to whole MM_STEP_BLOCK-thread blocks): every one of them
@@ -2699,6 +2708,11 @@ extern "C" int32_t mm_create(const MMConfig *cfg, int32_t E, int32_t N, int32_t 
   for (int64_t e = 0; e < E; e++) tmp[e] = cfg->seed + (uint64_t)(first_env + e);
   DeviceGuard dg(device);
   hipError_t rc = dg.rc;
+  if (rc == hipSuccess) {
+    int cus = 0;
+    rc = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    h->n_simd = 4 * cus;
+  }
   if (rc == hipSuccess) rc = hipMemcpy(h->state + h->lay.seed_offset, tmp, (size_t)E * 8u, hipMemcpyHostToDevice);
   free(tmp);
   if (rc == hipSuccess) rc = hipMalloc((void **)&h->dev_err, MM_LW_COUNT * sizeof(int));

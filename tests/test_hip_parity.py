@@ -76,6 +76,17 @@ def test_golden_tape(path):
     print(os.path.basename(path), json.dumps({k: float("%.3g" % v) for k, v in err.items()}))
 
 
+@pytest.mark.parametrize("path", [p for p in episode_files() if os.path.basename(p).startswith("ipm_")], ids=lambda p: os.path.basename(p)[:-4])
+def test_golden_tape_split_step(path):
+    """The interior-point tapes once more through the SPLIT step (a one-env batch runs the fused kernel by itself: debug_flags
+    bit3 forces the phase kernels + sweep kernel), same bar: the reference's tape directly, 1e-9, no knife-edges."""
+    _, meta = load_episode(path)
+    if meta.get("n_hdv", 0):
+        pytest.skip("mixed traffic steps in the fused kernels only")
+    err = replay(lambda E, N, **kw: _gpu_env(E, N, debug_flags=8, **kw), path, tol=1e-9, max_knife_edges=0)
+    assert err["knife_edges"] == 0
+
+
 @pytest.mark.parametrize("path", episode_files("sc_*.npz"), ids=lambda p: os.path.basename(p)[:-4])
 def test_crash_scenarios_free_running(path):
     """test/cbf crash scenarios on the GPU, free-running: crash step / no-crash as in the reference."""
@@ -317,14 +328,18 @@ IPM_CASES = [("cbf-cav", 8, 0, 256, 110, True), ("cbf-avs_cint", 4, 0, 256, 110,
              ("cbf-cav", 9, 0, 64, 40, False), ("cbf-avs_cint", 6, 0, 128, 40, False), ("cbf-avs_cint", 12, 0, 64, 40, True)]
 
 
+@pytest.mark.parametrize("form", ["fused", "split"])
 @pytest.mark.parametrize("safety,N,n_hdv,E,steps,trace", IPM_CASES, ids=lambda c: str(c))
-def test_random_rollout_ipm_vs_oracle(safety, N, n_hdv, E, steps, trace):
-    """MM_QP_IPM fidelity mode inside step(): the in-kernel interior-point QP (every vehicle, every sub-step) against the
+def test_random_rollout_ipm_vs_oracle(safety, N, n_hdv, E, steps, trace, form):
+    """Interior-point mode inside step(): the in-kernel interior-point QP (every vehicle, every sub-step) against the
     oracle's general dense IPM, free-running with auto-reset, LC-heavy tape: every bit of state / obs / rewards, and the
-    per-sub-step status bits (is_optimal follows the IPM's status)."""
+    per-sub-step status bits (is_optimal follows the IPM's status).  Both forms of the step: the fused kernel (what a batch
+    this small runs by default) and the split step (phase kernels + lane-per-env sweep kernel; CAV-only batches)."""
+    if form == "split" and n_hdv:
+        pytest.skip("mixed traffic steps in the fused kernels only")
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5,
               obs_f64=True, seed=2024, auto_reset=True, n_hdv=n_hdv, qp_solver="ipm", trace=trace)
-    gpu, cpu = _gpu_env(E, N, **kw), oracle_env.OracleEnv(E, N, **kw)
+    gpu, cpu = _gpu_env(E, N, debug_flags=8 if form == "split" else 4, **kw), oracle_env.OracleEnv(E, N, **kw)
     gpu.reset(); cpu.reset()
     g = torch.Generator().manual_seed(77)
     p = torch.tensor([0.25, 0.3, 0.25, 0.1, 0.1])
@@ -350,7 +365,8 @@ def test_split_interior_point_step_equals_the_fused_kernel(safety, N, E):
     kernel's selection) occur."""
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5,
               qp_solver="ipm", seed=515, auto_reset=True, trace=True, obs_f64=True)
-    split, fused, slow = _gpu_env(E, N, **kw), _gpu_env(E, N, debug_flags=4, **kw), _gpu_env(E, N, debug_flags=1, **kw)
+    # (a batch this small steps in the fused kernel by default: bit3 forces the split step)
+    split, fused, slow = _gpu_env(E, N, debug_flags=8, **kw), _gpu_env(E, N, debug_flags=4, **kw), _gpu_env(E, N, debug_flags=8 | 1, **kw)
     for env in (split, fused, slow):
         env.reset()
     g = torch.Generator().manual_seed(3)
