@@ -1207,6 +1207,11 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
 #ifndef MM_IPM_WAVES
 #define MM_IPM_WAVES 2
 #endif
+// the fused interior-point kernels of CAV-only batches run only up to two fused waves per SIMD (larger batches take the split
+// step, steps_split below)
+#ifndef MM_IPM_CAV_WAVES
+#define MM_IPM_CAV_WAVES 2
+#endif
 #ifndef MM_SPLIT_WAVES
 #define MM_SPLIT_WAVES 2  // phase form of the step kernel (split interior-point step): 168 registers (3 waves) spill 85 of them
 #endif
@@ -1214,7 +1219,7 @@ template <int G, int SHIELD, bool MIXED>
 #ifndef MM_GENERAL_NONE_WAVES
 #define MM_GENERAL_NONE_WAVES 3  // mixed-traffic unshielded: 0.49 (2 waves) / 0.445 (3) / 0.51 ms (4)
 #endif
-constexpr int step_min_waves(bool ipm = false) { return SHIELD == MM_SHIELD_NONE ? (MIXED ? MM_GENERAL_NONE_WAVES : MM_NONE_WAVES) : (ipm ? MM_IPM_WAVES : MM_MIN_WAVES); }
+constexpr int step_min_waves(bool ipm = false) { return SHIELD == MM_SHIELD_NONE ? (MIXED ? MM_GENERAL_NONE_WAVES : MM_NONE_WAVES) : (ipm ? (MIXED ? MM_IPM_WAVES : MM_IPM_CAV_WAVES) : MM_MIN_WAVES); }
 // IPM: the MM_QP_IPM fidelity mode (the shield's QP by cvxopt's interior-point algorithm, include/mm_qp.h); carried by
 // general (MIXED) instantiations only, which run the literal sweep -- one QP per vehicle per sub-step, as the reference
 // TRACE: the per-sub-step trace planes (MMStepOut.trace, tests / profile export) are a compile-time property: the
