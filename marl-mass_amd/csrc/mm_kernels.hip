@@ -994,7 +994,10 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
   // and a global round trip per read is ~2 us for a lone wave.  [field][vehicle][lane]: the lanes of a wave read "vehicle o"
   // together and a gather "vehicle j(lane)" differs by whole 512-byte rows -- no bank conflicts either way.
   __shared__ double s_w[6][NV][64];  // SW_WX .. SW_WVX
-  __shared__ int s_pk[NV][64], s_meta[NV][64], s_cls[NV][64];
+  // (16-bit planes: with NV = 11 the wave's LDS stays under 40 KB = four single-wave workgroups per CU, one per SIMD)
+  __shared__ unsigned short s_pk[NV][64], s_meta[NV][64], s_cls[NV][64];
+  // SW_META packed into 9 bits: live | shield_on | needB | Vehicle flags (3 bits) << 3 | hl_action (0..4, 7 = None) << 6
+  auto pack_meta = [](int m) { const int hl = (m >> 16) & 255; return (unsigned short)((m & 7) | ((m >> 8) & 7) << 3 | (hl > 4 ? 7 : hl) << 6); };
   enum { PH_SETUP = 0, PH_RUN = 1, PH_FIN = 2, PH_DONE = 3 };
   int phase = e < c.E ? PH_SETUP : PH_DONE;
   unsigned long long ord_lo = ~0ull, ord_hi = ~0ull;  // sweep order, one byte per rank (0..7 | 8..15)
@@ -1010,9 +1013,9 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
         own_v[o] = sw_f(sb, SW_V, o, e); own_gvx[o] = sw_f(sb, SW_GVX, o, e); own_acc[o] = sw_f(sb, SW_ACCN, o, e); own_cpsi[o] = sw_f(sb, SW_CPSI, o, e);
 #pragma unroll
         for (int f = 0; f < 6; f++) s_w[f][o][ln] = sw_f(sb, f, o, e);
-        s_pk[o][ln] = sw_i(sb, SW_WPK, o, e);
-        s_meta[o][ln] = sw_i(sb, SW_META, o, e);
-        s_cls[o][ln] = sw_i(sb, SW_CLS, o, e);
+        s_pk[o][ln] = (unsigned short)sw_i(sb, SW_WPK, o, e);
+        s_meta[o][ln] = pack_meta(sw_i(sb, SW_META, o, e));
+        s_cls[o][ln] = (unsigned short)sw_i(sb, SW_CLS, o, e);
         const unsigned long long ob = sb.order[(long long)o * sb.Ep + e];
         if (o < 8) ord_lo = (ord_lo & ~(0xFFull << (8 * o))) | ob << (8 * o);
         else ord_hi = (ord_hi & ~(0xFFull << (8 * (o - 8)))) | ob << (8 * (o - 8));
@@ -1072,7 +1075,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
     if (serve && __any(phase == PH_FIN)) {
       if (phase == PH_FIN) {
         Veh v;
-        v.v = e_v; v.flags = (ego_meta >> 8) & 255; v.hl = (ego_meta >> 16) & 255;  // (all shield_post reads of the vehicle)
+        v.v = e_v; v.flags = (ego_meta >> 3) & 7; v.hl = ((ego_meta >> 6) & 7) == 7 ? (int)MM_HL_NONE : (ego_meta >> 6) & 7;  // (all shield_post reads of the vehicle)
         const ShieldOut so = shield_post<MASS>(c, v, ss, rw, q.x0, opt, true);
         if (so.bounds) atomicOr(c.err, MM_LATCH_QP_BOUNDS);
         const bool needB = (ego_meta & 4) != 0, use_B = so.veto && needB;
@@ -1082,7 +1085,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
         }
         double nv = e_v + so.acc * dt;
         nv = nv > 0 ? nv : 0;
-        s_w[SW_WX][ego][ln] = p_ax; s_w[SW_WY][ego][ln] = p_ay; s_w[SW_WH][ego][ln] = p_ah; s_pk[ego][ln] = p_apk;
+        s_w[SW_WX][ego][ln] = p_ax; s_w[SW_WY][ego][ln] = p_ay; s_w[SW_WH][ego][ln] = p_ah; s_pk[ego][ln] = (unsigned short)p_apk;
         s_w[SW_WHX][ego][ln] = p_h1x;
         s_w[SW_WGU][ego][ln] = slot_gu<MASS>(p_h1vx, MASS ? so.acc : kCbfAccLo, p_ag, dt);
         s_w[SW_WVX][ego][ln] = nv * p_ac;
@@ -2944,9 +2947,10 @@ static void launch_split_gs(MMHandle h, const int32_t *actions, const MMStepOut 
     // at half speed each while another CU holds three -- so every launch asks for dynamic LDS up to 40 KB per workgroup
     // (160 KB / 4): at most four per CU.
     auto pad = [](size_t used) { return (unsigned)(used < 40960 ? 40960 - used : 0); };
-    constexpr size_t kPerVeh = 6 * 64 * sizeof(double) + 3 * 64 * sizeof(int);  // s_w + s_pk / s_meta / s_cls of sweep_kernel
+    constexpr size_t kPerVeh = 6 * 64 * sizeof(double) + 3 * 64 * sizeof(unsigned short);  // s_w + s_pk / s_meta / s_cls of sweep_kernel
     if (h->N <= 4) hipLaunchKernelGGL((sweep_kernel<4, MASS>), dim3(sgrid), dim3(64), pad(4 * kPerVeh), s, dc, h->sweep, kb, out->trace, ds.A);
     else if (h->N <= 8) hipLaunchKernelGGL((sweep_kernel<8, MASS>), dim3(sgrid), dim3(64), pad(8 * kPerVeh), s, dc, h->sweep, kb, out->trace, ds.A);
+    else if (h->N <= 11) hipLaunchKernelGGL((sweep_kernel<11, MASS>), dim3(sgrid), dim3(64), pad(11 * kPerVeh), s, dc, h->sweep, kb, out->trace, ds.A);  // (38 KB: density 3 = up to 11 vehicles)
     else hipLaunchKernelGGL((sweep_kernel<12, MASS>), dim3(sgrid), dim3(64), pad(12 * kPerVeh), s, dc, h->sweep, kb, out->trace, ds.A);
   }
 }
