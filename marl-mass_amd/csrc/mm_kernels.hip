@@ -63,9 +63,10 @@ struct DevState {
 // vehicle: act / predict / commit / collide / rewards) with one launch of sweep_kernel (lane per ENV: the front-to-back
 // shield sweep with its interior-point QPs) after each act / predict.  Planes are [field][vehicle a][env e] with the env
 // index innermost: a sweep wave (64 consecutive envs) reads "field f of vehicle a" as one coalesced 512-byte line.
+// (What the sweep needs of the vehicles' pre-step STATE -- pose, speed, g.vx, previous safe acceleration, history records --
+// it reads from the state planes themselves: the phase kernel stores them before the sweep launch anyway.)
 enum {
-  SW_WX, SW_WY, SW_WH, SW_WHX, SW_WGU, SW_WVX,                   // what the others see of a vehicle: pre-step view, overwritten by the sweep when it commits
-  SW_V, SW_CPSI, SW_GVX, SW_ACCN, SW_H1X, SW_H1VX,               // the vehicle's own shield inputs (speed, cos heading, g.vx, nominal acceleration, state_hist[-1])
+  SW_CPSI, SW_ACCN,                                              // cos of the pre-step heading, the clipped nominal acceleration
   SW_AX, SW_AY, SW_AH, SW_ACPSI, SW_AGVX, SW_ASTEER, SW_ASPSI,   // candidate A (nominal steering): predicted post-state
   SW_BX, SW_BY, SW_BH, SW_BCPSI, SW_BGVX, SW_BSTEER, SW_BSPSI,   // candidate B (LC-veto steering), only where META says needB
   SW_ACC,                                                        // sweep -> phase kernel: the decided acceleration
@@ -974,9 +975,10 @@ MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
 // now (multi_agent_state), build the CBF rows, solve the QP (include/mm_qp.h, resumable: every lane of the wave is at its
 // own iteration of its own QP), evaluate status / veto / flags (shield_post), publish the ego's committed post-state for
 // the egos behind it.  64 envs per wave, every lane busy until its env is through.
-// What the others see of a vehicle lives in the SweepBuf view planes (SW_W*): written pre-step by the phase kernel, replaced
-// by the post-step view when the vehicle commits.  All lanes of a wave read "vehicle o" of their envs together (coalesced);
-// the ego's own fields and the three selected neighbours are gathers.
+// What the others see of a vehicle ("view": pose, pose code, history record x, its g*u product, longitudinal speed) lives in
+// LDS, one column per env: built at the top of the launch from the state planes the phase kernel stored (pre-step view),
+// replaced by the post-step view when the vehicle commits.  All lanes of a wave read "vehicle o" of their envs together; the
+// ego's own fields and the three selected neighbours are gathers (conflict-free: whole 512-byte rows apart).
 // NV: compile-time bound on N (the classification keys live in registers).
 #ifndef MM_SWEEP_GATE_T
 #define MM_SWEEP_GATE_T 48
@@ -985,7 +987,9 @@ MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
 #define MM_SWEEP_GATE_W 8
 #endif
 template <int NV, bool MASS>
-__global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int k, double *trace, long long A) {
+__global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, SweepBuf sb, int k, double *trace) {
+  const long long A = st.A;
+  enum { W_X = 0, W_Y, W_H, W_HX, W_GU, W_VX };  // the view planes of s_w
   const int ln = threadIdx.x;
   const long long e = (long long)blockIdx.x * 64 + ln;
   const int N = sb.N;
@@ -993,7 +997,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
   // The views of the env's vehicles live in LDS for the whole sweep, one column per lane (= env): every ego reads all of them,
   // and a global round trip per read is ~2 us for a lone wave.  [field][vehicle][lane]: the lanes of a wave read "vehicle o"
   // together and a gather "vehicle j(lane)" differs by whole 512-byte rows -- no bank conflicts either way.
-  __shared__ double s_w[6][NV][64];  // SW_WX .. SW_WVX
+  __shared__ double s_w[6][NV][64];  // W_X .. W_VX
   // (16-bit planes: with NV = 11 the wave's LDS stays under 40 KB = four single-wave workgroups per CU, one per SIMD)
   __shared__ unsigned short s_pk[NV][64], s_meta[NV][64], s_cls[NV][64];
   // SW_META packed into 9 bits: live | shield_on | needB | Vehicle flags (3 bits) << 3 | hl_action (0..4, 7 = None) << 6
@@ -1010,9 +1014,14 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
 #pragma unroll
     for (int o = 0; o < NV; o++) {
       if (o < N) {
-        own_v[o] = sw_f(sb, SW_V, o, e); own_gvx[o] = sw_f(sb, SW_GVX, o, e); own_acc[o] = sw_f(sb, SW_ACCN, o, e); own_cpsi[o] = sw_f(sb, SW_CPSI, o, e);
-#pragma unroll
-        for (int f = 0; f < 6; f++) s_w[f][o][ln] = sw_f(sb, f, o, e);
+        // the pre-step view the literal sweep starts from (the fused kernel's serial form: wx .. wgu), from the state planes
+        const long long i = e * N + o;
+        own_v[o] = st.F[MM_F_SPEED * A + i]; own_gvx[o] = st.F[MM_F_G_VX * A + i];
+        own_acc[o] = sw_f(sb, SW_ACCN, o, e); own_cpsi[o] = sw_f(sb, SW_CPSI, o, e);
+        s_w[W_X][o][ln] = st.F[MM_F_X * A + i]; s_w[W_Y][o][ln] = st.F[MM_F_Y * A + i]; s_w[W_H][o][ln] = st.F[MM_F_HEADING * A + i];
+        s_w[W_HX][o][ln] = st.F[MM_F_H2_X * A + i];
+        s_w[W_GU][o][ln] = slot_gu<MASS>(st.F[MM_F_H2_VX * A + i], MASS ? st.F[MM_F_SAFE_ACC * A + i] : kCbfAccLo, own_gvx[o], dt);
+        s_w[W_VX][o][ln] = own_v[o] * own_cpsi[o];
         s_pk[o][ln] = (unsigned short)sw_i(sb, SW_WPK, o, e);
         s_meta[o][ln] = pack_meta(sw_i(sb, SW_META, o, e));
         s_cls[o][ln] = (unsigned short)sw_i(sb, SW_CLS, o, e);
@@ -1085,10 +1094,10 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
         }
         double nv = e_v + so.acc * dt;
         nv = nv > 0 ? nv : 0;
-        s_w[SW_WX][ego][ln] = p_ax; s_w[SW_WY][ego][ln] = p_ay; s_w[SW_WH][ego][ln] = p_ah; s_pk[ego][ln] = (unsigned short)p_apk;
-        s_w[SW_WHX][ego][ln] = p_h1x;
-        s_w[SW_WGU][ego][ln] = slot_gu<MASS>(p_h1vx, MASS ? so.acc : kCbfAccLo, p_ag, dt);
-        s_w[SW_WVX][ego][ln] = nv * p_ac;
+        s_w[W_X][ego][ln] = p_ax; s_w[W_Y][ego][ln] = p_ay; s_w[W_H][ego][ln] = p_ah; s_pk[ego][ln] = (unsigned short)p_apk;
+        s_w[W_HX][ego][ln] = p_h1x;
+        s_w[W_GU][ego][ln] = slot_gu<MASS>(p_h1vx, MASS ? so.acc : kCbfAccLo, p_ag, dt);
+        s_w[W_VX][ego][ln] = nv * p_ac;
         sw_f(sb, SW_ACC, ego, e) = so.acc;
         sw_i(sb, SW_RES, ego, e) = 1 | (so.veto ? 2 : 0) | (use_B ? 4 : 0) | (so.flags & 255) << 8;
         if (trace) {
@@ -1125,10 +1134,10 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
           for (int o = 0; o < NV; o++) {
             if (o == ego) { e_v = own_v[o]; e_gvx = own_gvx[o]; e_acc = own_acc[o]; cpsi = own_cpsi[o]; }
           }
-          p_h1x = sw_f(sb, SW_H1X, ego, e); p_h1vx = sw_f(sb, SW_H1VX, ego, e);
+          p_h1x = st.F[MM_F_H1_X * A + e * N + ego]; p_h1vx = st.F[MM_F_H1_VX * A + e * N + ego];
           p_ax = sw_f(sb, SW_AX, ego, e); p_ay = sw_f(sb, SW_AY, ego, e); p_ah = sw_f(sb, SW_AH, ego, e);
           p_ag = sw_f(sb, SW_AGVX, ego, e); p_ac = sw_f(sb, SW_ACPSI, ego, e); p_apk = sw_i(sb, SW_APK, ego, e);
-          const double ex = s_w[SW_WX][ego][ln], ey = s_w[SW_WY][ego][ln];
+          const double ex = s_w[W_X][ego][ln], ey = s_w[W_Y][ego][ln];
           const int epk = s_pk[ego][ln];
           // slot selection: the phase kernel's (all egos of the batch classified at once, lane per vehicle), or -- once a vehicle
           // ahead committed candidate B, so that this ego sees a pose the phase kernel did not assume -- classified here
@@ -1145,7 +1154,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
 #pragma unroll
               for (int o = 0; o < NV; o++) {
                 const bool other = (s_meta[o][ln] & 1) != 0 && o != ego;  // (o >= N: meta 0)
-                const Rel rl = relate(ex, ey, epk, other, s_w[SW_WX][o][ln], s_w[SW_WY][o][ln], s_w[SW_WH][o][ln], s_pk[o][ln]);
+                const Rel rl = relate(ex, ey, epk, other, s_w[W_X][o][ln], s_w[W_Y][o][ln], s_w[W_H][o][ln], s_pk[o][ln]);
                 key[o] = rl.key;
                 // first in sorted order per class: smaller key, ties by creation index (ascending o: a strict < keeps the earlier one)
                 if (rl.cls == 1 && rl.key < k_ol) { k_ol = rl.key; j_ol = o; }
@@ -1165,9 +1174,9 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, SweepBuf sb, int
             }
           }
           const int s_ol = nb.has_ol ? j_ol : 0, s_oa = nb.has_oa ? j_oa : 0, s_oar = nb.has_oar ? j_oar : 0;
-          nb.ol_x = s_w[SW_WHX][s_ol][ln]; nb.ol_gu = s_w[SW_WGU][s_ol][ln];
-          nb.oa_x = s_w[SW_WHX][s_oa][ln]; nb.oa_gu = s_w[SW_WGU][s_oa][ln];
-          nb.oar_x = s_w[SW_WX][s_oar][ln]; nb.oar_vx = s_w[SW_WVX][s_oar][ln];
+          nb.ol_x = s_w[W_HX][s_ol][ln]; nb.ol_gu = s_w[W_GU][s_ol][ln];
+          nb.oa_x = s_w[W_HX][s_oa][ln]; nb.oa_gu = s_w[W_GU][s_oa][ln];
+          nb.oar_x = s_w[W_X][s_oar][ln]; nb.oar_vx = s_w[W_VX][s_oar][ln];
           nb.ol_vx = nb.oa_vx = nb.ol_acc = nb.ol_g = nb.oa_acc = nb.oa_g = 0;  // folded into ol_gu / oa_gu
           obstacle_override<MASS>(nb, ex, ey);
           Veh v;
@@ -1547,13 +1556,10 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
         if (valid) {
           sw_i(sb, SW_META, a, e) = (live ? 1 : 0) | (shield_on ? 2 : 0) | (needB ? 4 : 0) | (v.flags & 255) << 8 | (v.hl & 255) << 16;
           if (live) {
-            // the pre-step view the literal sweep starts from (serial form below: wx .. wgu)
-            sw_f(sb, SW_WX, a, e) = v.x; sw_f(sb, SW_WY, a, e) = v.y; sw_f(sb, SW_WH, a, e) = v.h; sw_i(sb, SW_WPK, a, e) = pk_self;
-            sw_f(sb, SW_WHX, a, e) = s_cold[C_H2X][tid];
-            sw_f(sb, SW_WGU, a, e) = slot_gu<MASS>(s_cold[C_H2VX][tid], MASS ? s_cold[C_SACC][tid] : kCbfAccLo, v.gvx, dt);
-            sw_f(sb, SW_WVX, a, e) = v.v * cpsi;
-            sw_f(sb, SW_V, a, e) = v.v; sw_f(sb, SW_CPSI, a, e) = cpsi; sw_f(sb, SW_GVX, a, e) = v.gvx; sw_f(sb, SW_ACCN, a, e) = v.act_acc;
-            sw_f(sb, SW_H1X, a, e) = s_cold[C_H1X][tid]; sw_f(sb, SW_H1VX, a, e) = s_cold[C_H1VX][tid];
+            // (the pre-step view the literal sweep starts from -- serial form below: wx .. wgu -- is built by the sweep kernel from
+            // the state planes this launch stores; only what is not state goes through the hand-off planes)
+            sw_i(sb, SW_WPK, a, e) = pk_self;
+            sw_f(sb, SW_CPSI, a, e) = cpsi; sw_f(sb, SW_ACCN, a, e) = v.act_acc;
             sw_f(sb, SW_AX, a, e) = cA.x; sw_f(sb, SW_AY, a, e) = cA.y; sw_f(sb, SW_AH, a, e) = cA.h; sw_i(sb, SW_APK, a, e) = cA.pk;
             sw_f(sb, SW_ACPSI, a, e) = cA.cpsi; sw_f(sb, SW_AGVX, a, e) = cA.gvx; sw_f(sb, SW_ASTEER, a, e) = v.act_steer; sw_f(sb, SW_ASPSI, a, e) = cA.spsi;
             if (needB) {
@@ -2084,10 +2090,16 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
   if constexpr (SPLIT) {
     if (kb < c.nsub) {  // more sub-steps to come: the state planes carry the vehicles to the next launch
       if (valid && v.present) {
-        v.h1x = s_cold[C_H1X][tid]; v.h1vx = s_cold[C_H1VX][tid]; v.h2x = s_cold[C_H2X][tid]; v.h2vx = s_cold[C_H2VX][tid];
-        v.safe_steer = s_cold[C_SSTEER][tid]; v.safe_acc = s_cold[C_SACC][tid];
-        v.tspeed = s_cold[C_TSPEED][tid];
-        store_veh(st, i, v, false);
+        if (kb == 0) {  // (nothing committed yet: only what the act half changes)
+          st.F[MM_F_TARGET_SPEED * A + i] = s_cold[C_TSPEED][tid];
+          st.B[MM_B_TARGET_LANE * A + i] = (uint8_t)v.tlane; st.B[MM_B_SPEED_INDEX * A + i] = (uint8_t)v.sidx;
+          st.B[MM_B_HL_ACTION * A + i] = (uint8_t)v.hl;
+        } else {
+          v.h1x = s_cold[C_H1X][tid]; v.h1vx = s_cold[C_H1VX][tid]; v.h2x = s_cold[C_H2X][tid]; v.h2vx = s_cold[C_H2VX][tid];
+          v.safe_steer = s_cold[C_SSTEER][tid]; v.safe_acc = s_cold[C_SACC][tid];
+          v.tspeed = s_cold[C_TSPEED][tid];
+          store_veh(st, i, v, false);
+        }
       }
       if (e < st.E && a == 0) { st.I[MM_E_STEPS * st.E + e] = steps; st.I[MM_E_TIME * st.E + e] = time; }
       return;
@@ -2948,10 +2960,10 @@ static void launch_split_gs(MMHandle h, const int32_t *actions, const MMStepOut 
     // (160 KB / 4): at most four per CU.
     auto pad = [](size_t used) { return (unsigned)(used < 40960 ? 40960 - used : 0); };
     constexpr size_t kPerVeh = 6 * 64 * sizeof(double) + 3 * 64 * sizeof(unsigned short);  // s_w + s_pk / s_meta / s_cls of sweep_kernel
-    if (h->N <= 4) hipLaunchKernelGGL((sweep_kernel<4, MASS>), dim3(sgrid), dim3(64), pad(4 * kPerVeh), s, dc, h->sweep, kb, out->trace, ds.A);
-    else if (h->N <= 8) hipLaunchKernelGGL((sweep_kernel<8, MASS>), dim3(sgrid), dim3(64), pad(8 * kPerVeh), s, dc, h->sweep, kb, out->trace, ds.A);
-    else if (h->N <= 11) hipLaunchKernelGGL((sweep_kernel<11, MASS>), dim3(sgrid), dim3(64), pad(11 * kPerVeh), s, dc, h->sweep, kb, out->trace, ds.A);  // (38 KB: density 3 = up to 11 vehicles)
-    else hipLaunchKernelGGL((sweep_kernel<12, MASS>), dim3(sgrid), dim3(64), pad(12 * kPerVeh), s, dc, h->sweep, kb, out->trace, ds.A);
+    if (h->N <= 4) hipLaunchKernelGGL((sweep_kernel<4, MASS>), dim3(sgrid), dim3(64), pad(4 * kPerVeh), s, dc, ds, h->sweep, kb, out->trace);
+    else if (h->N <= 8) hipLaunchKernelGGL((sweep_kernel<8, MASS>), dim3(sgrid), dim3(64), pad(8 * kPerVeh), s, dc, ds, h->sweep, kb, out->trace);
+    else if (h->N <= 11) hipLaunchKernelGGL((sweep_kernel<11, MASS>), dim3(sgrid), dim3(64), pad(11 * kPerVeh), s, dc, ds, h->sweep, kb, out->trace);  // (38 KB: density 3 = up to 11 vehicles)
+    else hipLaunchKernelGGL((sweep_kernel<12, MASS>), dim3(sgrid), dim3(64), pad(12 * kPerVeh), s, dc, ds, h->sweep, kb, out->trace);
   }
 }
 #if MM_TU == 0
