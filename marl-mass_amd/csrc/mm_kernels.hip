@@ -84,6 +84,7 @@ struct SweepBuf {
   int *I;          // [SW_I_COUNT][N][Ep]
   uint8_t *order;  // [N][Ep]: creation index of the live vehicle with sweep rank r (x descending, stable), 0xFF: none
   uint8_t *envf;   // [Ep]: the env is still stepping (no terminal sub-step so far in this policy step)
+  uint8_t *urgent; // [Ep]: scheduling hint only (never a result): the env had a QP that ran past 12 iterations in its last sweep
   long long Ep;    // E rounded up to whole waves
   int N;
 };
@@ -986,6 +987,9 @@ MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
 #ifndef MM_SWEEP_GATE_W
 #define MM_SWEEP_GATE_W 8
 #endif
+#ifndef MM_SWEEP_GATE_WU  // ... and a lane on the launch's critical path (see `urgent`) at most this many
+#define MM_SWEEP_GATE_WU 3
+#endif
 template <int NV, bool MASS>
 __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, SweepBuf sb, int k, double *trace) {
   const long long A = st.A;
@@ -1061,6 +1065,13 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
 #endif
   int since = 0;       // trips since lanes were last served (wave-uniform)
   bool serve = false;
+  // An env with a QP on its way to the iteration cap (past 12 iterations: none of the QPs that converge takes that long) is on
+  // the launch's critical path -- the launch ends with its slowest env -- so (HSS) its lane is served after at most
+  // MM_SWEEP_GATE_WU trips, and with it whoever else is waiting.  Such envs tend to stay that way for several sub-steps (the
+  // same vehicle keeps braking at its bound): the flag of the last sweep is the prior.  A scheduling hint: results do not
+  // depend on it.  Measured at 65 536 x 8 (ms per step, without / with): HSS 1.70 / 1.48 - 1.52 for WU = 1 .. 6; MASS 1.93 /
+  // 1.96 - 2.00 (more envs are urgent at a time and the extra services cost the wave more than the slowest lane gains): HSS only.
+  bool urgent = phase != PH_DONE && sb.urgent[e] != 0, slow_now = false;
   for (int trip = 0;; trip++) {
     SCOUNT(4);
     if (trip > (MM_QP_MAXITERS + 3 + MM_SWEEP_GATE_W) * (NV + 1)) { atomicOr(c.err, MM_LATCH_INTERNAL); break; }  // cannot happen: every trip advances a QP or the rank, or counts towards a service
@@ -1068,6 +1079,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
     if (phase == PH_RUN) {
       const int stop = mm_qp_top(&q, &rs);
       if (stop || sing) { phase = PH_FIN; opt = stop == 1 && !sing; }
+      if (q.iters > 12) { urgent = true; slow_now = true; }
     }
     SSTAMP(0);
     // Lanes whose QP stopped (or that have none yet) are SERVED -- (2) post / publish, (3) set up the next ego -- together:
@@ -1076,7 +1088,8 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
     {
       const int n_wait = __popcll(__ballot(phase == PH_FIN || phase == PH_SETUP)), n_run = __popcll(__ballot(phase == PH_RUN));
       since += 1;
-      serve = n_wait > 0 && (n_wait >= MM_SWEEP_GATE_T || n_run == 0 || since >= MM_SWEEP_GATE_W);
+      serve = n_wait > 0 && (n_wait >= MM_SWEEP_GATE_T || n_run == 0 || since >= MM_SWEEP_GATE_W ||
+                             (!MASS && since >= MM_SWEEP_GATE_WU && __any(urgent && (phase == PH_FIN || phase == PH_SETUP))));
       if (serve) since = 0;
     }
     // (2) a QP stopped: everything after solvers.qp returned (cbf.py:134-161, decentral_layer.py:493-518 / :721-764), then
@@ -1200,6 +1213,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
     }
     SSTAMP(3);
   }
+  if (e < c.E) sb.urgent[e] = slow_now ? 1 : 0;
 #ifdef MM_STAMPS
   if ((threadIdx.x & 63) < 8 && blockIdx.x < 4096) g_stamps_s[blockIdx.x * 8 + (threadIdx.x & 63)] += _t_acc;
 #endif
@@ -2679,7 +2693,7 @@ static int check_cfg(const MMConfig *c, int N, char *err) {
 static hipError_t ensure_sweep(MMHandle_ *h) {
   if (h->sweep_mem || !steps_split(h)) return hipSuccess;
   const uint64_t Ep = ((uint64_t)h->E + 63u) & ~(uint64_t)63u, N = (uint64_t)h->N;
-  const uint64_t bF = align256(Ep * N * 8u * SW_F_COUNT), bI = align256(Ep * N * 4u * SW_I_COUNT), bO = align256(Ep * N), bE = align256(Ep);
+  const uint64_t bF = align256(Ep * N * 8u * SW_F_COUNT), bI = align256(Ep * N * 4u * SW_I_COUNT), bO = align256(Ep * N), bE = 2 * align256(Ep);
   unsigned char *m = nullptr;
   hipError_t rc = hipMalloc((void **)&m, bF + bI + bO + bE);
   if (rc != hipSuccess) return rc;
@@ -2687,6 +2701,7 @@ static hipError_t ensure_sweep(MMHandle_ *h) {
   if (rc != hipSuccess) { (void)hipFree(m); return rc; }
   h->sweep_mem = m;
   h->sweep.F = (double *)m; h->sweep.I = (int *)(m + bF); h->sweep.order = m + bF + bI; h->sweep.envf = m + bF + bI + bO;
+  h->sweep.urgent = h->sweep.envf + align256(Ep);
   h->sweep.Ep = (long long)Ep; h->sweep.N = h->N;
   return hipSuccess;
 }
