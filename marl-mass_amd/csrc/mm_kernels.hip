@@ -1230,6 +1230,11 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
 #ifndef MM_NONE_WAVES
 #define MM_NONE_WAVES 3
 #endif
+// unshielded kernels in groups of at least this many lanes run at 2 waves / SIMD (256 registers): at 168 the 12- / 16-lane
+// instantiations spill 56 - 116 VGPRs
+#ifndef MM_NONE_WIDE_G
+#define MM_NONE_WIDE_G 99
+#endif
 #ifndef MM_IPM_WAVES
 #define MM_IPM_WAVES 2
 #endif
@@ -1245,7 +1250,7 @@ template <int G, int SHIELD, bool MIXED>
 #ifndef MM_GENERAL_NONE_WAVES
 #define MM_GENERAL_NONE_WAVES 3  // mixed-traffic unshielded: 0.49 (2 waves) / 0.445 (3) / 0.51 ms (4)
 #endif
-constexpr int step_min_waves(bool ipm = false) { return SHIELD == MM_SHIELD_NONE ? (MIXED ? MM_GENERAL_NONE_WAVES : MM_NONE_WAVES) : (ipm ? (MIXED ? MM_IPM_WAVES : MM_IPM_CAV_WAVES) : MM_MIN_WAVES); }
+constexpr int step_min_waves(bool ipm = false) { return SHIELD == MM_SHIELD_NONE ? (G >= MM_NONE_WIDE_G ? 2 : (MIXED ? MM_GENERAL_NONE_WAVES : MM_NONE_WAVES)) : (ipm ? (MIXED ? MM_IPM_WAVES : MM_IPM_CAV_WAVES) : MM_MIN_WAVES); }
 // IPM: the MM_QP_IPM fidelity mode (the shield's QP by cvxopt's interior-point algorithm, include/mm_qp.h); carried by
 // general (MIXED) instantiations only, which run the literal sweep -- one QP per vehicle per sub-step, as the reference
 // TRACE: the per-sub-step trace planes (MMStepOut.trace, tests / profile export) are a compile-time property: the
