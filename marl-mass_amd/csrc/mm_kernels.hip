@@ -987,6 +987,9 @@ MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
 #ifndef MM_SWEEP_GATE_W
 #define MM_SWEEP_GATE_W 8
 #endif
+#ifndef MM_SWEEP_SPEC_AT  // the iteration at which a still-running QP is taken to be on its way to the cap (see "SPECULATION")
+#define MM_SWEEP_SPEC_AT 13
+#endif
 #ifndef MM_SWEEP_GATE_WU  // ... and a lane on the launch's critical path (see `urgent`) at most this many
 #define MM_SWEEP_GATE_WU 3
 #endif
@@ -1037,6 +1040,19 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
       }
     }
   }
+  // the views as the phase kernel left them, once more (a failed speculation: the env is swept again; what the sweep never
+  // writes -- own_*, s_meta, s_cls, the order -- is still in place)
+  auto reload_views = [&]() {
+    for (int o = 0; o < N; o++) {
+      const long long i = e * N + o;
+      const double gvx = st.F[MM_F_G_VX * A + i];
+      s_w[W_X][o][ln] = st.F[MM_F_X * A + i]; s_w[W_Y][o][ln] = st.F[MM_F_Y * A + i]; s_w[W_H][o][ln] = st.F[MM_F_HEADING * A + i];
+      s_w[W_HX][o][ln] = st.F[MM_F_H2_X * A + i];
+      s_w[W_GU][o][ln] = slot_gu<MASS>(st.F[MM_F_H2_VX * A + i], MASS ? st.F[MM_F_SAFE_ACC * A + i] : kCbfAccLo, gvx, dt);
+      s_w[W_VX][o][ln] = st.F[MM_F_SPEED * A + i] * sw_f(sb, SW_CPSI, o, e);
+      s_pk[o][ln] = (unsigned short)sw_i(sb, SW_WPK, o, e);
+    }
+  };
   int r = 0;         // next sweep rank to look at
   int ego = 0;       // creation index of the vehicle whose QP this lane is solving
   int ego_meta = 0;
@@ -1072,20 +1088,91 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
   // depend on it.  Measured at 65 536 x 8 (ms per step, without / with): HSS 1.70 / 1.48 - 1.52 for WU = 1 .. 6; MASS 1.93 /
   // 1.96 - 2.00 (more envs are urgent at a time and the extra services cost the wave more than the slowest lane gains): HSS only.
   bool urgent = phase != PH_DONE && sb.urgent[e] != 0, slow_now = false;
+  // SPECULATION on the QPs that run towards the iteration cap.  Every QP of this path that converges does so within 11
+  // iterations; one still running at iteration MM_SWEEP_SPEC_AT (13) is infeasible without the slack and ends -- whether the
+  // frozen-iterate certificate stops it at ~29 or it runs to 100 -- at d = -h2 with status "unknown" (include/mm_qp.h).  Waiting for
+  // that is what the launch's slowest envs do (chains of such QPs: a hard-braking leader makes its follower's row infeasible
+  // too).  So the lane ASSUMES that outcome, goes on with the env, and puts the QP itself -- state and residuals -- into the
+  // wave's verification queue in LDS.  When every env of the wave is through, the queued QPs are iterated to their real stop
+  // side by side, one per lane (top / bottom only: ~16 of the kernel's cheapest trips instead of ~16 per QP on its env's
+  // critical path).  A stop that is not ("unknown", x0 == the assumed value bit for bit) marks the owner's env: it is swept
+  // again from the state planes without speculation (everything it wrote is written again).  Results are therefore those of
+  // the literal loop by construction; debug_flags bit4 makes every assumption wrong (the rollback under test), bit5 switches
+  // speculation off.  (Built first with idle lanes verifying DURING the sweep: fewer trips, but the merge of a second QP
+  // state into the main loop cost more than it saved -- profiles/r04/variants.jsonl.)
+  constexpr int VQ_CAP = NV <= 8 ? 16 : 1;  // (a full queue: the lane simply iterates on; LDS: 40 KB per wave in all)
+  __shared__ double s_vq[VQ_CAP][40];
+  __shared__ int s_vq_own[VQ_CAP], s_redo[64];
+  s_redo[ln] = 0;
+  int vq_head = 0, vq_tail = 0;  // ring indices, wave-uniform
+  // (MASS with up to 8 vehicles only.  HSS has no chains -- a vehicle's QP reads nobody's decision -- and its sweep lost more to
+  // the extra code than the shorter waits gained: 1.49 -> 1.60 ms at 65 536 x 8; with NV = 11 the LDS has room for four queue
+  // entries only: 3.06 -> 3.12 ms at traffic_density 3)
+  constexpr bool kSpec = MASS && NV <= 8;
+  bool nospec = !kSpec || (c.debug_flags & 32) != 0;
+  int help_owner = 0;
+  double help_pred = 0.0;
   for (int trip = 0;; trip++) {
     SCOUNT(4);
-    if (trip > (MM_QP_MAXITERS + 3 + MM_SWEEP_GATE_W) * (NV + 1)) { atomicOr(c.err, MM_LATCH_INTERNAL); break; }  // cannot happen: every trip advances a QP or the rank, or counts towards a service
+    if (trip > 3 * (MM_QP_MAXITERS + 3 + MM_SWEEP_GATE_W) * (NV + 1)) { atomicOr(c.err, MM_LATCH_INTERNAL); break; }  // cannot happen: every trip advances a QP or the rank, or counts towards a service
     // (1) cvxopt's stopping test for the running QPs
+    bool push = false;
     if (phase == PH_RUN) {
       const int stop = mm_qp_top(&q, &rs);
-      if (stop || sing) { phase = PH_FIN; opt = stop == 1 && !sing; }
-      if (q.iters > 12) { urgent = true; slow_now = true; }
+      {
+        if (stop || sing) { phase = PH_FIN; opt = stop == 1 && !sing; }
+        else if (kSpec && q.iters == MM_SWEEP_SPEC_AT && !nospec && q.a > 0.0) {
+          // Assume only where the outcome is all but certain (a wrong assumption costs the wave a second sweep of the env):
+          // the lower bound is not degenerate (h2 = 0: a stopped vehicle -- that QP converges, slowly), the CBF row is clearly
+          // infeasible (predicted slack s* = -a h2 - h_c > 1e-4: a smaller one converges, "optimal", after 20 - 90
+          // iterations), and -h2 keeps clear of the lattice on which the dual residual could vanish (mm_qp_frozen's condition
+          // (4), from the predicted multiplier 1e18 s*).  20 M random QPs of the shield's shapes: 10.1 M assumed, 6 wrong at
+          // s* > 1e-6 (all below 2e-5).
+          const double hc = (q.m4 && q.h3 < q.h0) ? q.h3 : q.h0, sstar = (-q.a * q.h2) - hc;
+          if (q.h2 > 1e-3 && sstar > 1e-4) {
+            const int ex = ilogb(q.a * 1e18 * sstar) - 2;
+            const double y = ldexp(q.h2, 53 - ex);
+            push = fabs(y) < 0x1p+51 && ldexp(fabs(y - rint(y)), ex - 53) > 1e-6;
+          }
+        }
+        if (q.iters > 12) { urgent = true; slow_now = true; }
+      }
     }
+#ifndef MM_SWEEP_NOSPEC_CODE
+    if constexpr (kSpec) {
+      const unsigned long long pm = __ballot(push);
+      if (pm) {  // hand the QPs over (as many as the queue has room for; the others simply iterate on)
+        const int room = VQ_CAP - (vq_tail - vq_head), idx = __popcll(pm & ((1ull << ln) - 1ull));
+        if (push && idx < room) {
+          double *t = s_vq[(vq_tail + idx) % VQ_CAP];
+          double pred = -q.h2;
+          if (c.debug_flags & 16) pred = pred + 0x1p-30;
+          t[0] = q.a; t[1] = q.h0; t[2] = q.h1; t[3] = q.h2; t[4] = q.h3; t[5] = q.resz0; t[6] = q.x0; t[7] = q.x2; t[8] = q.gap;
+          t[9] = q.s0; t[10] = q.s1; t[11] = q.s2; t[12] = q.s3; t[13] = q.z0; t[14] = q.z1; t[15] = q.z2; t[16] = q.z3;
+          t[17] = q.d0; t[18] = q.d1; t[19] = q.d2; t[20] = q.d3; t[21] = q.di0; t[22] = q.di1; t[23] = q.di2; t[24] = q.di3;
+          t[25] = q.l0; t[26] = q.l1; t[27] = q.l2; t[28] = q.l3; t[29] = q.ax0; t[30] = q.ax2;
+          t[31] = rs.rx0; t[32] = rs.rx2; t[33] = rs.rz0; t[34] = rs.rz1; t[35] = rs.rz2; t[36] = rs.rz3;
+          t[37] = pred; t[38] = (double)(q.m4 | q.iters << 1);
+          s_vq_own[(vq_tail + idx) % VQ_CAP] = ln;
+          q.x0 = pred; opt = false; phase = PH_FIN;  // the assumed outcome: solvers.qp returned (d = -h2, "unknown")
+#ifdef MM_STAMPS
+          atomicAdd(&g_stamps_s[blockIdx.x % 4096 * 8 + 7], 1ull);
+#endif
+        }
+        const int n = __popcll(pm);
+        vq_tail += n < room ? n : room;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+#endif
     SSTAMP(0);
     // Lanes whose QP stopped (or that have none yet) are SERVED -- (2) post / publish, (3) set up the next ego -- together:
     // the wave executes those ~1 k instructions whenever one lane needs them, so a lone finisher waits up to
     // MM_SWEEP_GATE_W trips for company unless MM_SWEEP_GATE_T lanes are waiting or nothing else is running.
     {
+      // (n_run: lanes iterating a QP of their OWN env -- a lane that only has helpers for company is served at once)
       const int n_wait = __popcll(__ballot(phase == PH_FIN || phase == PH_SETUP)), n_run = __popcll(__ballot(phase == PH_RUN));
       since += 1;
       serve = n_wait > 0 && (n_wait >= MM_SWEEP_GATE_T || n_run == 0 || since >= MM_SWEEP_GATE_W ||
@@ -1207,7 +1294,54 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
     }
     SSTAMP(2);
     // (4) one interior-point iteration of every running QP
-    if (!__any(phase != PH_DONE)) break;
+    if (!__any(phase != PH_DONE)) {
+      // every env is through: the wave now VERIFIES what its lanes assumed -- lane j takes the j-th queued QP and iterates it
+      // to its real stop (top / bottom only: the cheapest trips of the kernel, all queued QPs side by side)
+      const int nq = kSpec ? vq_tail - vq_head : 0;
+      if (kSpec && nq > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bool helping = ln < nq;
+        if (helping) {
+          const double *t = s_vq[(vq_head + ln) % VQ_CAP];
+          q.a = t[0]; q.h0 = t[1]; q.h1 = t[2]; q.h2 = t[3]; q.h3 = t[4]; q.resz0 = t[5]; q.x0 = t[6]; q.x2 = t[7]; q.gap = t[8];
+          q.s0 = t[9]; q.s1 = t[10]; q.s2 = t[11]; q.s3 = t[12]; q.z0 = t[13]; q.z1 = t[14]; q.z2 = t[15]; q.z3 = t[16];
+          q.d0 = t[17]; q.d1 = t[18]; q.d2 = t[19]; q.d3 = t[20]; q.di0 = t[21]; q.di1 = t[22]; q.di2 = t[23]; q.di3 = t[24];
+          q.l0 = t[25]; q.l1 = t[26]; q.l2 = t[27]; q.l3 = t[28]; q.ax0 = t[29]; q.ax2 = t[30];
+          rs.rx0 = t[31]; rs.rx2 = t[32]; rs.rz0 = t[33]; rs.rz1 = t[34]; rs.rz2 = t[35]; rs.rz3 = t[36];
+          help_pred = t[37];
+          const int mi = (int)t[38];
+          q.m4 = mi & 1; q.iters = mi >> 1;
+          help_owner = s_vq_own[(vq_head + ln) % VQ_CAP];
+        }
+        vq_head = vq_tail;
+        while (__any(helping)) {
+          if (helping) {
+            const bool ok = mm_qp_bottom(&q, &rs) != 0;  // (the entry holds the state after a stopping test that said "go on")
+            const int stop = ok ? mm_qp_top(&q, &rs) : 2;
+            if (stop) {  // did it end where its owner assumed?
+              if (stop == 1 || __double_as_longlong(q.x0) != __double_as_longlong(help_pred)) s_redo[help_owner] = 1;
+              helping = false;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      // nothing left to do -- unless an assumption failed: those envs are swept again, literally
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const bool redo = kSpec && s_redo[ln] != 0;
+      if (!kSpec || !__any(redo)) break;
+      if (redo) {
+#ifdef MM_STAMPS
+        atomicAdd(&g_stamps_s[blockIdx.x % 4096 * 8 + 6], 1ull);
+#endif
+        s_redo[ln] = 0;
+        reload_views();
+        r = 0; dirty = (c.debug_flags & 1) != 0; nospec = true;
+        phase = PH_SETUP;
+      }
+      continue;
+    }
     if (__any(phase == PH_RUN)) {
       if (phase == PH_RUN) sing = mm_qp_bottom(&q, &rs) == 0;  // singular KKT matrix: the iterate stands, status "unknown"
     }
@@ -2979,11 +3113,11 @@ static void launch_split_gs(MMHandle h, const int32_t *actions, const MMStepOut 
     // at half speed each while another CU holds three -- so every launch asks for dynamic LDS up to 40 KB per workgroup
     // (160 KB / 4): at most four per CU.
     auto pad = [](size_t used) { return (unsigned)(used < 40960 ? 40960 - used : 0); };
-    constexpr size_t kPerVeh = 6 * 64 * sizeof(double) + 3 * 64 * sizeof(unsigned short);  // s_w + s_pk / s_meta / s_cls of sweep_kernel
-    if (h->N <= 4) hipLaunchKernelGGL((sweep_kernel<4, MASS>), dim3(sgrid), dim3(64), pad(4 * kPerVeh), s, dc, ds, h->sweep, kb, out->trace);
-    else if (h->N <= 8) hipLaunchKernelGGL((sweep_kernel<8, MASS>), dim3(sgrid), dim3(64), pad(8 * kPerVeh), s, dc, ds, h->sweep, kb, out->trace);
-    else if (h->N <= 11) hipLaunchKernelGGL((sweep_kernel<11, MASS>), dim3(sgrid), dim3(64), pad(11 * kPerVeh), s, dc, ds, h->sweep, kb, out->trace);  // (38 KB: density 3 = up to 11 vehicles)
-    else hipLaunchKernelGGL((sweep_kernel<12, MASS>), dim3(sgrid), dim3(64), pad(12 * kPerVeh), s, dc, ds, h->sweep, kb, out->trace);
+    constexpr size_t kPerVeh = 6 * 64 * sizeof(double) + 3 * 64 * sizeof(unsigned short);  // s_w + s_pk / s_meta / s_cls of sweep_kernel (+ ~3 KB: verification queue)
+    if (h->N <= 4) hipLaunchKernelGGL((sweep_kernel<4, MASS>), dim3(sgrid), dim3(64), pad(4 * kPerVeh + 5632), s, dc, ds, h->sweep, kb, out->trace);
+    else if (h->N <= 8) hipLaunchKernelGGL((sweep_kernel<8, MASS>), dim3(sgrid), dim3(64), pad(8 * kPerVeh + 5632), s, dc, ds, h->sweep, kb, out->trace);
+    else if (h->N <= 11) hipLaunchKernelGGL((sweep_kernel<11, MASS>), dim3(sgrid), dim3(64), pad(11 * kPerVeh + 1024), s, dc, ds, h->sweep, kb, out->trace);  // (38 KB: density 3 = up to 11 vehicles)
+    else hipLaunchKernelGGL((sweep_kernel<12, MASS>), dim3(sgrid), dim3(64), pad(12 * kPerVeh + 1024), s, dc, ds, h->sweep, kb, out->trace);
   }
 }
 #if MM_TU == 0

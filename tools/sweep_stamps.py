@@ -9,7 +9,7 @@ import torch
 from marl_mass_amd import VecMergeEnv, hip_library, _cabi as abi
 shield = sys.argv[1] if len(sys.argv) > 1 else "cbf-cav"
 E, N = int(os.environ.get("MM_STAMPS_E", "65536")), 8
-env = VecMergeEnv(E, N, config={"safety_guarantee": shield, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5, seed=1000, auto_reset=True, qp_solver="ipm")
+env = VecMergeEnv(E, N, config={"safety_guarantee": shield, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5, seed=1000, auto_reset=True, qp_solver="ipm", debug_flags=int(os.environ.get("MM_DEBUG_FLAGS", "0")))
 env.reset()
 env.env_i32[abi.EP["STEPS"]] = ((torch.arange(E, device="cuda:0") * 37) % 100).to(torch.int32)
 g = torch.Generator(device="cuda:0").manual_seed(123)
@@ -23,7 +23,7 @@ K = 20
 for t in range(K): env.step(ring[t % 8])
 torch.cuda.synchronize(); lib.mm_debug_read_sweep_stamps(buf, 1)
 launches = (E // 64) * K * 3
-names = ["stopping test", "post + publish", "setup", "iteration", "trips", "setup trips"]
+names = ["stopping test", "post + publish", "setup", "iteration", "trips", "setup trips", "re-swept envs (failed assumption)", "QPs handed to the verification queue"]
 out = {n: buf[k] / launches for k, n in enumerate(names)}
 out["unit"] = "s_memtime cycles (100 MHz ticks) resp. counts, per wave and sweep launch"
 print(json.dumps(out, indent=1))
