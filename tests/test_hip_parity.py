@@ -362,20 +362,24 @@ def test_split_interior_point_step_equals_the_fused_kernel(safety, N, E):
     per-sub-step trace (incl. every QP's rows and iterate), outputs -- as (a) the fused kernel with its wave-wide interior-point
     loop (debug_flags bit2) and (b) the sweep kernel classifying every ego itself instead of taking the phase kernel's slot
     selection (debug_flags bit0); LC-heavy action tape so that candidate-B commits (the case that invalidates the phase
-    kernel's selection) occur."""
+    kernel's selection) occur.  Also (c) the sweep kernel with every speculation on a capped QP deliberately WRONG (debug_flags
+    bit4: the assumed iterate is off by 2^-30, so every verification fails and the env is swept again literally -- the rollback
+    path) and (d) with speculation switched off (bit5)."""
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5,
               qp_solver="ipm", seed=515, auto_reset=True, trace=True, obs_f64=True)
     # (a batch this small steps in the fused kernel by default: bit3 forces the split step)
     split, fused, slow = _gpu_env(E, N, debug_flags=8, **kw), _gpu_env(E, N, debug_flags=4, **kw), _gpu_env(E, N, debug_flags=8 | 1, **kw)
-    for env in (split, fused, slow):
+    wrong, nospec = _gpu_env(E, N, debug_flags=8 | 16, **kw), _gpu_env(E, N, debug_flags=8 | 32, **kw)
+    for env in (split, fused, slow, wrong, nospec):
         env.reset()
     g = torch.Generator().manual_seed(3)
     p = torch.tensor([0.3, 0.2, 0.3, 0.1, 0.1])
-    committed_b = 0
+    committed_b = capped = 0
     for t in range(70):
         a = torch.multinomial(p, E * N, True, generator=g).view(E, N).int().cuda()
-        outs = [env.step(a) for env in (split, fused, slow)]
-        for other, name in ((fused, "fused"), (slow, "self-classifying sweep")):
+        outs = [env.step(a) for env in (split, fused, slow, wrong, nospec)]
+        capped += int((split.trace[:, abi.T["STATUS"]].nan_to_num().to(torch.int64) & (abi.ST_RAN | abi.ST_IS_OPTIMAL) == abi.ST_RAN).sum())
+        for other, name in ((fused, "fused"), (slow, "self-classifying sweep"), (wrong, "wrong assumptions, re-swept"), (nospec, "no speculation")):
             assert torch.equal(split.u8, other.u8) and torch.equal(split.env_i32, other.env_i32), (t, name)
             assert torch.equal(split.f64.nan_to_num(), other.f64.nan_to_num()), (t, name)
             assert torch.equal(split.trace.nan_to_num(nan=-7.0), other.trace.nan_to_num(nan=-7.0)), (t, name)
@@ -387,7 +391,9 @@ def test_split_interior_point_step_equals_the_fused_kernel(safety, N, E):
         tr = split.trace
         committed_b += int((tr[:, abi.T["SAFE_STEER"]].nan_to_num() != tr[:, abi.T["ACT_STEER"]].nan_to_num()).sum())
     assert committed_b > 0, "the tape must exercise candidate-B commits"
-    for env in (split, fused, slow):
+    if safety == "cbf-cav" and N <= 8:
+        assert capped > 0, "the tape must contain QPs that run towards the iteration cap (the speculation's subject)"
+    for env in (split, fused, slow, wrong, nospec):
         env.poll_errors()
 
 
