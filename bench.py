@@ -421,8 +421,8 @@ def main():
                          "traffic_unit": "bytes/launch: rocprofv3 PMC passes of this command, 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction), "
                                          "committed under profiles/ (see profiles/traffic.json: source)",
                          "alg_bytes_per_launch": E * N * b_alg,
-                         "kernel": "step_kernel" if args.qp_solver == "exact" or args.shield == "none" or args.hdv or args.mixed_traffic or E * (8 if N <= 8 else 16) // 64 <= 2048
-                         else "4 x step_kernel (phase form) + 3 x sweep_kernel (CAV-only interior-point step above two fused waves per SIMD)",
+                         "kernel": "step_kernel" if args.qp_solver == "exact" or args.shield == "none" or E * (2 if N <= 2 else 4 if N <= 4 else 8 if N <= 8 else 16) // 64 <= 2048
+                         else "4 x step_kernel (phase form) + 3 x sweep_kernel (interior-point step above two fused waves per SIMD)",
                          "kernel_ms": kern_ms, "alg_bytes_per_agent_step": b_alg,
                          "kernel_ms_note": "measured AFTER the timed region: %s between ONE HIP event pair on the launch stream, / launches "
                                            "= the kernel(s) of one mm_step + the device's dispatch gap (the rollout metrics are deferred: no "

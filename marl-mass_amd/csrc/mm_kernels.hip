@@ -73,7 +73,9 @@ enum {
   SW_F_COUNT
 };
 enum { SW_WPK, SW_APK, SW_BPK, SW_META, SW_RES, SW_CLS, SW_I_COUNT };
-// SW_META: bit0 live, bit1 shield_on, bit2 needB, bits 8..15 Vehicle flags, bits 16..23 hl_action
+// SW_META: bit0 live, bit1 shield_on, bit2 needB, bit3 HDV, bits 8..15 Vehicle flags, bits 16..23 hl_action
+// (an HDV has no decision: for it SW_RES bit4 says "an ego edited my history record" -- the on-ramp digital twin,
+// decentral_layer.py:164-184 -- and SW_ACC then holds the edited state_hist[-2].x)
 // SW_RES (written by the sweep for every ego it ran): bit0 ran, bit1 veto, bit2 committed candidate B, bits 8..15 new flags
 // SW_CLS: multi_agent_state's slot selection for this vehicle as ego, evaluated by the phase kernel for all vehicles at once
 //   (leader | front-adjacent << 4 | rear-adjacent << 8 creation indices, bits 12..14 the slot exists, bit 15 constrain_adj)
@@ -993,7 +995,10 @@ MM_DEV void trace_status(double *t, long long A, const ShieldOut &o) {
 #ifndef MM_SWEEP_GATE_WU  // ... and a lane on the launch's critical path (see `urgent`) at most this many
 #define MM_SWEEP_GATE_WU 3
 #endif
-template <int NV, bool MASS>
+// MIXED: the env may hold IDM / MOBIL vehicles.  They run no shield; when the sweep passes one it publishes its post-step view
+// (Road.step has stepped it), and an ego on ab0 that finds one on the ramp beside it shifts that vehicle's history record in
+// place -- the reference's "digital twin" (decentral_layer.py:162-184) -- which the later egos and the next sub-step see.
+template <int NV, bool MASS, bool MIXED = false>
 __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, SweepBuf sb, int k, double *trace) {
   const long long A = st.A;
   enum { W_X = 0, W_Y, W_H, W_HX, W_GU, W_VX };  // the view planes of s_w
@@ -1008,7 +1013,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
   // (16-bit planes: with NV = 11 the wave's LDS stays under 40 KB = four single-wave workgroups per CU, one per SIMD)
   __shared__ unsigned short s_pk[NV][64], s_meta[NV][64], s_cls[NV][64];
   // SW_META packed into 9 bits: live | shield_on | needB | Vehicle flags (3 bits) << 3 | hl_action (0..4, 7 = None) << 6
-  auto pack_meta = [](int m) { const int hl = (m >> 16) & 255; return (unsigned short)((m & 7) | ((m >> 8) & 7) << 3 | (hl > 4 ? 7 : hl) << 6); };
+  auto pack_meta = [](int m) { const int hl = (m >> 16) & 255; return (unsigned short)((m & 7) | ((m >> 8) & 7) << 3 | (hl > 4 ? 7 : hl) << 6 | ((m >> 3) & 1) << 9); };  // (bit 9: HDV)
   enum { PH_SETUP = 0, PH_RUN = 1, PH_FIN = 2, PH_DONE = 3 };
   int phase = e < c.E ? PH_SETUP : PH_DONE;
   unsigned long long ord_lo = ~0ull, ord_hi = ~0ull;  // sweep order, one byte per rank (0..7 | 8..15)
@@ -1027,10 +1032,12 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
         own_acc[o] = sw_f(sb, SW_ACCN, o, e); own_cpsi[o] = sw_f(sb, SW_CPSI, o, e);
         s_w[W_X][o][ln] = st.F[MM_F_X * A + i]; s_w[W_Y][o][ln] = st.F[MM_F_Y * A + i]; s_w[W_H][o][ln] = st.F[MM_F_HEADING * A + i];
         s_w[W_HX][o][ln] = st.F[MM_F_H2_X * A + i];
-        s_w[W_GU][o][ln] = slot_gu<MASS>(st.F[MM_F_H2_VX * A + i], MASS ? st.F[MM_F_SAFE_ACC * A + i] : kCbfAccLo, own_gvx[o], dt);
+        const int meta_o = sw_i(sb, SW_META, o, e);
+        const bool hdv_o = MIXED && (meta_o & 8) != 0;  // (an HDV's record: its action is taken as full braking, g.vx as 1)
+        s_w[W_GU][o][ln] = slot_gu<MASS>(st.F[MM_F_H2_VX * A + i], (MASS && !hdv_o) ? st.F[MM_F_SAFE_ACC * A + i] : kCbfAccLo, hdv_o ? 1.0 : own_gvx[o], dt);
         s_w[W_VX][o][ln] = own_v[o] * own_cpsi[o];
         s_pk[o][ln] = (unsigned short)sw_i(sb, SW_WPK, o, e);
-        s_meta[o][ln] = pack_meta(sw_i(sb, SW_META, o, e));
+        s_meta[o][ln] = pack_meta(meta_o);
         s_cls[o][ln] = (unsigned short)sw_i(sb, SW_CLS, o, e);
         const unsigned long long ob = sb.order[(long long)o * sb.Ep + e];
         if (o < 8) ord_lo = (ord_lo & ~(0xFFull << (8 * o))) | ob << (8 * o);
@@ -1058,7 +1065,10 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
   int ego_meta = 0;
   bool sing = false, opt = false;
   // the phase kernel's slot selection (SW_CLS) holds for an ego as long as every vehicle ahead of it committed candidate A
-  bool dirty = (c.debug_flags & 1) != 0;  // (debug_flags bit0: classify here always -- the validation form of this kernel)
+  // (general kernels carry no parallel-form classification: the sweep always classifies itself there)
+  bool dirty = MIXED || (c.debug_flags & 1) != 0;  // (debug_flags bit0: classify here always -- the validation form of this kernel)
+  unsigned hdv_stepped = 0, hdv_shifted = 0;  // per vehicle: the HDV's published view is the post-step one / its record was edited since
+  bool hss_collab = false;                    // HSS: vehicle.is_collaborating = cbf.constrain_adj of a twin (:181)
   double e_v = 0;  // the ego's speed (shield_post and the published view read it again after the QP)
   // what the ego publishes when it commits: fetched while its QP iterates
   double p_h1x = 0, p_h1vx = 0, p_ax = 0, p_ay = 0, p_ah = 0, p_ag = 0, p_ac = 0;
@@ -1108,7 +1118,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
   // (MASS with up to 8 vehicles only.  HSS has no chains -- a vehicle's QP reads nobody's decision -- and its sweep lost more to
   // the extra code than the shorter waits gained: 1.49 -> 1.60 ms at 65 536 x 8; with NV = 11 the LDS has room for four queue
   // entries only: 3.06 -> 3.12 ms at traffic_density 3)
-  constexpr bool kSpec = MASS && NV <= 8;
+  constexpr bool kSpec = MASS && NV <= 8 && !MIXED;
   bool nospec = !kSpec || (c.debug_flags & 32) != 0;
   int help_owner = 0;
   double help_pred = 0.0;
@@ -1185,7 +1195,8 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
       if (phase == PH_FIN) {
         Veh v;
         v.v = e_v; v.flags = (ego_meta >> 3) & 7; v.hl = ((ego_meta >> 6) & 7) == 7 ? (int)MM_HL_NONE : (ego_meta >> 6) & 7;  // (all shield_post reads of the vehicle)
-        const ShieldOut so = shield_post<MASS>(c, v, ss, rw, q.x0, opt, true);
+        ShieldOut so = shield_post<MASS>(c, v, ss, rw, q.x0, opt, true);
+        if (MIXED && hss_collab) so.flags |= MM_FLAG_IS_COLLABORATING;
         if (so.bounds) atomicOr(c.err, MM_LATCH_QP_BOUNDS);
         const bool needB = (ego_meta & 4) != 0, use_B = so.veto && needB;
         if (use_B) {  // (rare: the LC-veto candidate is fetched on demand)
@@ -1224,8 +1235,27 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
           if (o == 0xFF) { r = N; break; }
           ego_meta = s_meta[o][ln];
           if (ego_meta & 2) { ego = o; break; }
+          if (MIXED && (ego_meta & 0x201) == 0x201) {
+            // an HDV steps when the sweep reaches it (no shield): from here on the egos see its post-step pose, and its
+            // state_hist[-2] is the record it held as [-1] before (IDMVehicleHist, behavior.py:505-521); its speed entry
+            // stays the pre-step one, like the fused kernel's view
+            s_w[W_X][o][ln] = sw_f(sb, SW_AX, o, e); s_w[W_Y][o][ln] = sw_f(sb, SW_AY, o, e); s_w[W_H][o][ln] = sw_f(sb, SW_AH, o, e);
+            s_pk[o][ln] = (unsigned short)sw_i(sb, SW_APK, o, e);
+            s_w[W_HX][o][ln] = st.F[MM_F_H1_X * A + e * N + o];
+            s_w[W_GU][o][ln] = slot_gu<MASS>(st.F[MM_F_H1_VX * A + e * N + o], kCbfAccLo, 1.0, dt);
+            hdv_stepped |= 1u << o; hdv_shifted &= ~(1u << o);
+          }
         }
         if (ego == 0xFF) {
+          if constexpr (MIXED) {  // what the egos did to the HDVs' records goes back to the phase kernel
+            for (int o = 0; o < N; o++) {
+              const int m = s_meta[o][ln];
+              if ((m & 0x201) != 0x201) continue;
+              const bool ed = ((hdv_stepped & hdv_shifted) >> o) & 1u;
+              if (ed) sw_f(sb, SW_ACC, o, e) = s_w[W_HX][o][ln];
+              sw_i(sb, SW_RES, o, e) = ed ? 16 : 0;
+            }
+          }
           phase = PH_DONE;
         } else {
           // what the ego will publish: global loads issued now, consumed when its QP has stopped
@@ -1251,11 +1281,14 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
               double k_ol = INFINITY, k_oa = INFINITY, k_oar = INFINITY;
               bool cadj = false;
               j_ol = j_oa = j_oar = -1;
+              unsigned twins = 0;  // vehicles in the digital-twin class (general kernels)
 #pragma unroll
               for (int o = 0; o < NV; o++) {
                 const bool other = (s_meta[o][ln] & 1) != 0 && o != ego;  // (o >= N: meta 0)
-                const Rel rl = relate(ex, ey, epk, other, s_w[W_X][o][ln], s_w[W_Y][o][ln], s_w[W_H][o][ln], s_pk[o][ln]);
+                const Rel rl = relate(ex, ey, epk, other, s_w[W_X][o][ln], s_w[W_Y][o][ln], s_w[W_H][o][ln], s_pk[o][ln],
+                                      MIXED && (s_meta[o][ln] & 0x200) != 0);
                 key[o] = rl.key;
+                if (MIXED && rl.cls == 4) twins |= 1u << o;
                 // first in sorted order per class: smaller key, ties by creation index (ascending o: a strict < keeps the earlier one)
                 if (rl.cls == 1 && rl.key < k_ol) { k_ol = rl.key; j_ol = o; }
                 if (rl.cls == 2 && rl.key < k_oa) { k_oa = rl.key; j_oa = o; cadj = rl.cflag; }
@@ -1271,6 +1304,30 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
               }
               nb.has_ol = j_ol >= 0 && pos_ol < 5; nb.has_oa = j_oa >= 0 && pos_oa < 5; nb.has_oar = j_oar >= 0 && pos_oar < 5;
               nb.constrain_adj = MASS && nb.has_oa && cadj;
+              if constexpr (MIXED) {
+                // digital twins (decentral_layer.py:162-184): EVERY HDV of that class among the 5 nearest gets its record
+                // shifted by half the ego's longitudinal speed, in place; the LAST one in sorted order ends up in s_oa (the
+                // branch has no `is None` guard) with cbf.constrain_adj = True
+                hss_collab = false;
+                if (twins) {
+                  const double e_vx = s_w[W_VX][ego][ln];  // vehicle.velocity[0] of the ego
+                  int best = -1, best_pos = -1;
+#pragma unroll
+                  for (int o = 0; o < NV; o++) {
+                    if ((twins >> o) & 1u) {
+                      int pos = 0;
+#pragma unroll
+                      for (int o2 = 0; o2 < NV; o2++) pos += (key[o2] < key[o] || (key[o2] == key[o] && o2 < o)) ? 1 : 0;
+                      if (pos < 5) {
+                        s_w[W_HX][o][ln] = s_w[W_HX][o][ln] + 0.5 * e_vx;
+                        hdv_shifted |= 1u << o;
+                        if (pos > best_pos) { best_pos = pos; best = o; }
+                      }
+                    }
+                  }
+                  if (best >= 0) { nb.has_oa = true; j_oa = best; nb.constrain_adj = MASS; hss_collab = !MASS; }
+                }
+              }
             }
           }
           const int s_ol = nb.has_ol ? j_ol : 0, s_oa = nb.has_oa ? j_oa : 0, s_oar = nb.has_oar ? j_oar : 0;
@@ -1406,7 +1463,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
   constexpr bool SHIELDED = LC && (SHIELD != MM_SHIELD_NONE);
   constexpr bool MASS = (SHIELD == MM_SHIELD_MASS);
   static_assert(!IPM || SHIELDED, "the IPM mode lives in shielded kernels");
-  static_assert(!SPLIT || (IPM && !MIXED), "the split form exists for the CAV-only interior-point kernels");
+  static_assert(!SPLIT || IPM, "the split form exists for the interior-point kernels");
   // Form of the shield sweep.  Every CAV-only shielded kernel (HSS and MASS) runs the parallel fixed-point form with the
   // literal front-to-back sweep compiled in as fallback (a vehicle moving backwards in x) and as the validation form
   // (debug_flags bit0); the general kernels (HDVs / steer_vel) and the MASS IPM kernels carry the literal sweep ONLY
@@ -1535,7 +1592,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
       // thing acted-upon state an HDV reads is other vehicles' target_lane_index (ongoing-LC abort
       // test, :193-206): it sees the post-act value of vehicles ahead of it in the sweep, the pre-act
       // value of the others; HDV decisions ahead feed HDVs behind -> small fixed point on tl_post.
-      if (__any(hdv && live)) {
+      if (head && __any(hdv && live)) {
         const bool acting = hdv && live && !v.crashed;
         // the sine-lane offset of my position, for the HDVs that scan lane kb0 (an ego's own lane only: the side lane of a
         // lane change is bc0 / bc1); one sine per vehicle instead of one per (ego, partner) pair
@@ -1630,8 +1687,8 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
       }
       // one steering_control for every vehicle that steers this sub-step: the CAVs, and the HDVs that acted (a crashed HDV
       // keeps its last action)
-      if (live && (!hdv || !v.crashed)) steer_lane(v, sv && !hdv, st_t);
-      if (hdv && live) v.gvx += dt;  // IDMVehicle.step: self.timer += dt (behavior.py:102-109)
+      if (head && live && (!hdv || !v.crashed)) steer_lane(v, sv && !hdv, st_t);
+      if (head && hdv && live) v.gvx += dt;  // IDMVehicle.step: self.timer += dt (behavior.py:102-109)
     }
     if (live && head) clip_actions(v, LC && !hdv, st_t);
     STAMP(1);  // act
@@ -1687,6 +1744,10 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
         // commit half of sub-step k: what its act half (previous launch) left in the hand-off planes -- the clipped nominal
         // acceleration and the candidate images -- goes back where the fused form keeps it
         v.act_acc = sw_f(sb, SW_ACCN, a, e);
+        if (MIXED && hdv) {  // an HDV's own action (store_veh keeps it in the safe_* planes) and the twin edit of its record
+          v.act_steer = sw_f(sb, SW_ASTEER, a, e);
+          if (sw_i(sb, SW_RES, a, e) & 16) s_cold[C_H1X][tid] = sw_f(sb, SW_ACC, a, e);  // (decentral_layer.py:164-184: state_hist[-2] edited in place)
+        }
         s_cold[C_A + 0][tid] = sw_f(sb, SW_AX, a, e); s_cold[C_A + 1][tid] = sw_f(sb, SW_AY, a, e); s_cold[C_A + 2][tid] = sw_f(sb, SW_AH, a, e);
         cold_i(C_A + 3, tid) = sw_i(sb, SW_APK, a, e); s_cold[C_A + 4][tid] = sw_f(sb, SW_ACPSI, a, e); s_cold[C_A + 5][tid] = sw_f(sb, SW_ASTEER, a, e);
         s_cold[C_A + 6][tid] = sw_f(sb, SW_AGVX, a, e); s_cold[C_A + 7][tid] = sw_f(sb, SW_ASPSI, a, e);
@@ -1707,7 +1768,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
         make_B();  // (eagerly, like the literal sweep: the sweep kernel decides the vetoes)
         const int n_live = __popc(group_ballot<G>(live, gb));
         if (valid) {
-          sw_i(sb, SW_META, a, e) = (live ? 1 : 0) | (shield_on ? 2 : 0) | (needB ? 4 : 0) | (v.flags & 255) << 8 | (v.hl & 255) << 16;
+          sw_i(sb, SW_META, a, e) = (live ? 1 : 0) | (shield_on ? 2 : 0) | (needB ? 4 : 0) | (hdv ? 8 : 0) | (v.flags & 255) << 8 | (v.hl & 255) << 16;
           if (live) {
             // (the pre-step view the literal sweep starts from -- serial form below: wx .. wgu -- is built by the sweep kernel from
             // the state planes this launch stores; only what is not state goes through the hand-off planes)
@@ -2243,7 +2304,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
   if constexpr (SPLIT) {
     if (kb < c.nsub) {  // more sub-steps to come: the state planes carry the vehicles to the next launch
       if (valid && v.present) {
-        if (kb == 0) {  // (nothing committed yet: only what the act half changes)
+        if (kb == 0 && !MIXED) {  // (nothing committed yet: only what the act half changes; general kernels: an HDV's action and timer too)
           st.F[MM_F_TARGET_SPEED * A + i] = s_cold[C_TSPEED][tid];
           st.B[MM_B_TARGET_LANE * A + i] = (uint8_t)v.tlane; st.B[MM_B_SPEED_INDEX * A + i] = (uint8_t)v.sidx;
           st.B[MM_B_HL_ACTION * A + i] = (uint8_t)v.hl;
@@ -2251,7 +2312,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
           v.h1x = s_cold[C_H1X][tid]; v.h1vx = s_cold[C_H1VX][tid]; v.h2x = s_cold[C_H2X][tid]; v.h2vx = s_cold[C_H2VX][tid];
           v.safe_steer = s_cold[C_SSTEER][tid]; v.safe_acc = s_cold[C_SACC][tid];
           v.tspeed = s_cold[C_TSPEED][tid];
-          store_veh(st, i, v, false);
+          store_veh(st, i, v, sv);
         }
       }
       if (e < st.E && a == 0) { st.I[MM_E_STEPS * st.E + e] = steps; st.I[MM_E_TIME * st.E + e] = time; }
@@ -2758,7 +2819,7 @@ static bool needs_general(const MMHandle_ *h) {  // HDVs can appear, or steer_ve
 // more than two fused waves per SIMD.  debug_flags bit2 keeps the fused kernel, bit3 forces the split step at any size
 // (validation / A-B timing: same results either way).
 static bool steps_split(const MMHandle_ *h) {
-  if (!(h->cfg.env_kind == MM_ENV_V1 && h->cfg.shield != MM_SHIELD_NONE && h->cfg.qp_solver == MM_QP_IPM && !needs_general(h))) return false;
+  if (!(h->cfg.env_kind == MM_ENV_V1 && h->cfg.shield != MM_SHIELD_NONE && h->cfg.qp_solver == MM_QP_IPM)) return false;
   if (h->cfg.debug_flags & 4) return false;
   if (h->cfg.debug_flags & 8) return true;
   const int g = h->N <= 2 ? 2 : (h->N <= 4 ? 4 : (h->N <= 8 ? 8 : 16));
@@ -3092,10 +3153,10 @@ static void launch_step_t(MMHandle h, const int32_t *actions, const MMStepOut *o
     hipLaunchKernelGGL((step_kernel<G, KIND, SHIELD, MIXED, IPM, false>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dev_cfg(h), dev_state(h),
                        actions, *out, h->metrics ? h->metrics_partial : nullptr, h->sweep, 0);
 }
-#if MM_TU == 0 || MM_TU == 6
+#if MM_TU == 0 || MM_TU == 6 || MM_TU == 7
 // The split interior-point step (SweepBuf, sweep_kernel): nsub + 1 phase launches with a sweep launch after each act half.
-// All on the caller's stream: each launch reads what the previous one wrote.
-template <int G, int SHIELD>
+// All on the caller's stream: each launch reads what the previous one wrote.  (MIXED: the general kernels -- HDVs / steer_vel.)
+template <int G, int SHIELD, bool MIXED>
 static void launch_split_gs(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   const long long threads = (long long)h->E * G;
   const unsigned grid = kPow2<G> ? (unsigned)((threads + MM_STEP_BLOCK - 1) / MM_STEP_BLOCK)
@@ -3105,7 +3166,7 @@ static void launch_split_gs(MMHandle h, const int32_t *actions, const MMStepOut 
   const unsigned sgrid = (unsigned)((h->E + 63) / 64);
   constexpr bool MASS = SHIELD == MM_SHIELD_MASS;
   for (int kb = 0; kb <= dc.nsub; kb++) {
-    hipLaunchKernelGGL((step_kernel<G, MM_ENV_V1, SHIELD, false, true, true, true>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dc, ds, actions,
+    hipLaunchKernelGGL((step_kernel<G, MM_ENV_V1, SHIELD, MIXED, true, true, true>), dim3(grid), dim3(MM_STEP_BLOCK), 0, s, dc, ds, actions,
                        *out, h->metrics ? h->metrics_partial : nullptr, h->sweep, kb);
     if (kb == dc.nsub) break;
     // One sweep wave per SIMD is the design point (65 536 envs = 1 024 waves = the chip's SIMDs; the kernel is bound by the
@@ -3114,19 +3175,17 @@ static void launch_split_gs(MMHandle h, const int32_t *actions, const MMStepOut 
     // (160 KB / 4): at most four per CU.
     auto pad = [](size_t used) { return (unsigned)(used < 40960 ? 40960 - used : 0); };
     constexpr size_t kPerVeh = 6 * 64 * sizeof(double) + 3 * 64 * sizeof(unsigned short);  // s_w + s_pk / s_meta / s_cls of sweep_kernel (+ ~3 KB: verification queue)
-    if (h->N <= 4) hipLaunchKernelGGL((sweep_kernel<4, MASS>), dim3(sgrid), dim3(64), pad(4 * kPerVeh + 5632), s, dc, ds, h->sweep, kb, out->trace);
-    else if (h->N <= 8) hipLaunchKernelGGL((sweep_kernel<8, MASS>), dim3(sgrid), dim3(64), pad(8 * kPerVeh + 5632), s, dc, ds, h->sweep, kb, out->trace);
-    else if (h->N <= 11) hipLaunchKernelGGL((sweep_kernel<11, MASS>), dim3(sgrid), dim3(64), pad(11 * kPerVeh + 1024), s, dc, ds, h->sweep, kb, out->trace);  // (38 KB: density 3 = up to 11 vehicles)
-    else hipLaunchKernelGGL((sweep_kernel<12, MASS>), dim3(sgrid), dim3(64), pad(12 * kPerVeh + 1024), s, dc, ds, h->sweep, kb, out->trace);
+    if (h->N <= 4) hipLaunchKernelGGL((sweep_kernel<4, MASS, MIXED>), dim3(sgrid), dim3(64), pad(4 * kPerVeh + 5632), s, dc, ds, h->sweep, kb, out->trace);
+    else if (h->N <= 8) hipLaunchKernelGGL((sweep_kernel<8, MASS, MIXED>), dim3(sgrid), dim3(64), pad(8 * kPerVeh + 5632), s, dc, ds, h->sweep, kb, out->trace);
+    else if (h->N <= 11) hipLaunchKernelGGL((sweep_kernel<11, MASS, MIXED>), dim3(sgrid), dim3(64), pad(11 * kPerVeh + 1024), s, dc, ds, h->sweep, kb, out->trace);  // (38 KB: density 3 = up to 11 vehicles)
+    else hipLaunchKernelGGL((sweep_kernel<12, MASS, MIXED>), dim3(sgrid), dim3(64), pad(12 * kPerVeh + 1024), s, dc, ds, h->sweep, kb, out->trace);
   }
 }
-#if MM_TU == 0
-static
-#endif
-void mm_launch_step_split(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+template <bool MIXED>
+static void launch_split_all(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   const bool mass = h->cfg.shield == MM_SHIELD_MASS;
   switch (g) {
-#define MM_SPLIT_CASE(GG) case GG: if (mass) launch_split_gs<GG, MM_SHIELD_MASS>(h, actions, out, s); else launch_split_gs<GG, MM_SHIELD_HSS>(h, actions, out, s); break;
+#define MM_SPLIT_CASE(GG) case GG: if (mass) launch_split_gs<GG, MM_SHIELD_MASS, MIXED>(h, actions, out, s); else launch_split_gs<GG, MM_SHIELD_HSS, MIXED>(h, actions, out, s); break;
 #ifdef MM_ONLY_G
     MM_SPLIT_CASE(MM_ONLY_G)
 #else
@@ -3136,6 +3195,24 @@ void mm_launch_step_split(MMHandle h, int g, const int32_t *actions, const MMSte
     default: break;
   }
 }
+#if MM_TU == 7
+void mm_launch_step_split_general(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s) { launch_split_all<true>(h, g, actions, out, s); }
+#elif MM_TU == 6
+void mm_launch_step_split_general(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s);
+void mm_launch_step_split(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+  if (needs_general(h)) mm_launch_step_split_general(h, g, actions, out, s);  // HDVs / steer_vel: the kernels that carry IDM / MOBIL
+  else launch_split_all<false>(h, g, actions, out, s);
+}
+#else  // single-TU tuning build
+static void mm_launch_step_split(MMHandle h, int g, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
+#ifdef MM_ONLY_MIXED
+  launch_split_all<MM_ONLY_MIXED>(h, g, actions, out, s);
+#else
+  if (needs_general(h)) launch_split_all<true>(h, g, actions, out, s);
+  else launch_split_all<false>(h, g, actions, out, s);
+#endif
+}
+#endif
 #endif
 template <int G, bool MIXED>
 static void launch_step_m(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
@@ -3199,7 +3276,7 @@ void mm_launch_step_lanes(MMHandle h, int g, const int32_t *actions, const MMSte
 #endif
 }
 #endif
-#if MM_TU == 4 || MM_TU == 5 || MM_TU == 6
+#if MM_TU == 4 || MM_TU == 5 || MM_TU == 6 || MM_TU == 7
 #elif MM_TU == 2
 void mm_launch_step_general(MMHandle h, const int32_t *actions, const MMStepOut *out, hipStream_t s) {
   switch (group_size(h->N)) {

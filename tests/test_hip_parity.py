@@ -80,9 +80,6 @@ def test_golden_tape(path):
 def test_golden_tape_split_step(path):
     """The interior-point tapes once more through the SPLIT step (a one-env batch runs the fused kernel by itself: debug_flags
     bit3 forces the phase kernels + sweep kernel), same bar: the reference's tape directly, 1e-9, no knife-edges."""
-    _, meta = load_episode(path)
-    if meta.get("n_hdv", 0):
-        pytest.skip("mixed traffic steps in the fused kernels only")
     err = replay(lambda E, N, **kw: _gpu_env(E, N, debug_flags=8, **kw), path, tol=1e-9, max_knife_edges=0)
     assert err["knife_edges"] == 0
 
@@ -334,9 +331,7 @@ def test_random_rollout_ipm_vs_oracle(safety, N, n_hdv, E, steps, trace, form):
     """Interior-point mode inside step(): the in-kernel interior-point QP (every vehicle, every sub-step) against the
     oracle's general dense IPM, free-running with auto-reset, LC-heavy tape: every bit of state / obs / rewards, and the
     per-sub-step status bits (is_optimal follows the IPM's status).  Both forms of the step: the fused kernel (what a batch
-    this small runs by default) and the split step (phase kernels + lane-per-env sweep kernel; CAV-only batches)."""
-    if form == "split" and n_hdv:
-        pytest.skip("mixed traffic steps in the fused kernels only")
+    this small runs by default) and the split step (phase kernels + lane-per-env sweep kernel)."""
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5,
               obs_f64=True, seed=2024, auto_reset=True, n_hdv=n_hdv, qp_solver="ipm", trace=trace)
     gpu, cpu = _gpu_env(E, N, debug_flags=8 if form == "split" else 4, **kw), oracle_env.OracleEnv(E, N, **kw)
@@ -356,8 +351,9 @@ def test_random_rollout_ipm_vs_oracle(safety, N, n_hdv, E, steps, trace, form):
     gpu.poll_errors(); cpu.poll_errors()  # check_bounds never fired
 
 
-@pytest.mark.parametrize("safety,N,E", [("cbf-cav", 8, 200), ("cbf-avs_cint", 4, 256), ("cbf-cav", 11, 70), ("cbf-cav", 6, 130), ("cbf-avs_cint", 2, 64)])
-def test_split_interior_point_step_equals_the_fused_kernel(safety, N, E):
+@pytest.mark.parametrize("safety,N,E,n_hdv", [("cbf-cav", 8, 200, 0), ("cbf-avs_cint", 4, 256, 0), ("cbf-cav", 11, 70, 0), ("cbf-cav", 6, 130, 0),
+                                                ("cbf-avs_cint", 2, 64, 0), ("cbf-cav", 8, 128, 4), ("cbf-avs_cint", 7, 128, 3), ("cbf-cav", 11, 64, 5)])
+def test_split_interior_point_step_equals_the_fused_kernel(safety, N, E, n_hdv):
     """The interior-point mode of a CAV-only batch steps as phase kernels + the lane-per-env sweep kernel.  Same bits -- state,
     per-sub-step trace (incl. every QP's rows and iterate), outputs -- as (a) the fused kernel with its wave-wide interior-point
     loop (debug_flags bit2) and (b) the sweep kernel classifying every ego itself instead of taking the phase kernel's slot
@@ -366,7 +362,7 @@ def test_split_interior_point_step_equals_the_fused_kernel(safety, N, E):
     bit4: the assumed iterate is off by 2^-30, so every verification fails and the env is swept again literally -- the rollback
     path) and (d) with speculation switched off (bit5)."""
     kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125, cbf_tau=0.5,
-              qp_solver="ipm", seed=515, auto_reset=True, trace=True, obs_f64=True)
+              qp_solver="ipm", seed=515, auto_reset=True, trace=True, obs_f64=True, n_hdv=n_hdv)
     # (a batch this small steps in the fused kernel by default: bit3 forces the split step)
     split, fused, slow = _gpu_env(E, N, debug_flags=8, **kw), _gpu_env(E, N, debug_flags=4, **kw), _gpu_env(E, N, debug_flags=8 | 1, **kw)
     wrong, nospec = _gpu_env(E, N, debug_flags=8 | 16, **kw), _gpu_env(E, N, debug_flags=8 | 32, **kw)
@@ -391,7 +387,7 @@ def test_split_interior_point_step_equals_the_fused_kernel(safety, N, E):
         tr = split.trace
         committed_b += int((tr[:, abi.T["SAFE_STEER"]].nan_to_num() != tr[:, abi.T["ACT_STEER"]].nan_to_num()).sum())
     assert committed_b > 0, "the tape must exercise candidate-B commits"
-    if safety == "cbf-cav" and N <= 8:
+    if safety == "cbf-cav" and N <= 8 and not n_hdv:
         assert capped > 0, "the tape must contain QPs that run towards the iteration cap (the speculation's subject)"
     for env in (split, fused, slow, wrong, nospec):
         env.poll_errors()
