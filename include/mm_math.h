@@ -104,19 +104,34 @@ MMM_FN double mmm_fma_c(double p, double z, double c) {
 #define MMM_L10 0x1.8618618618618p-5 /* 0.047619047619047616 */
 #define MMM_L11 0x1.642c8590b2164p-5 /* 0.043478260869565216 */
 
+/* Experiment (profiles/r04/variants.jsonl): Horner coefficients fetched from constant memory with scalar loads (one
+ * s_load_dwordx16 per polynomial) instead of two s_mov_b32 per coefficient.  -DMMM_COEF_TABLES, device builds only. */
+#if defined(MMM_COEF_TABLES) && defined(__HIP_DEVICE_COMPILE__)
+#define MMM_TABLE(name, ...) __attribute__((weak)) __constant__ double name[] = {__VA_ARGS__}; /* (not const, not static: else folded back into literals) */
+#define MMM_K(name, i, lit) (name[i])
+#else
+#define MMM_TABLE(name, ...)
+#define MMM_K(name, i, lit) (lit)
+#endif
+MMM_TABLE(mmm_t_sin, MMM_S7, MMM_S6, MMM_S5, MMM_S4, MMM_S3, MMM_S2, MMM_S1)
+MMM_TABLE(mmm_t_cos, MMM_C8, MMM_C7, MMM_C6, MMM_C5, MMM_C4, MMM_C3, MMM_C2)
+MMM_TABLE(mmm_t_atan, MMM_A10, MMM_A9, MMM_A8, MMM_A7, MMM_A6, MMM_A5, MMM_A4, MMM_A3, MMM_A2, MMM_A1)
+MMM_TABLE(mmm_t_exp, MMM_E14, MMM_E13, MMM_E12, MMM_E11, MMM_E10, MMM_E9, MMM_E8, MMM_E7, MMM_E6, MMM_E5, MMM_E4, MMM_E3, MMM_E2)
+MMM_TABLE(mmm_t_log, MMM_L11, MMM_L10, MMM_L9, MMM_L8, MMM_L7, MMM_L6, MMM_L5, MMM_L4, MMM_L3, MMM_L2, MMM_L1)
+
 /* sin / cos kernels on |r| <= pi/4 (Taylor to r^15 / r^16) */
 MMM_FN double mmm_ksin(double r) {
   double z = r * r;
-  double p = MMM_S7;
-  p = mmm_fma_c(p, z, MMM_S6); p = mmm_fma_c(p, z, MMM_S5); p = mmm_fma_c(p, z, MMM_S4);
-  p = mmm_fma_c(p, z, MMM_S3); p = mmm_fma_c(p, z, MMM_S2); p = mmm_fma_c(p, z, MMM_S1);
+  double p = MMM_K(mmm_t_sin, 0, MMM_S7);
+  p = mmm_fma_c(p, z, MMM_K(mmm_t_sin, 1, MMM_S6)); p = mmm_fma_c(p, z, MMM_K(mmm_t_sin, 2, MMM_S5)); p = mmm_fma_c(p, z, MMM_K(mmm_t_sin, 3, MMM_S4));
+  p = mmm_fma_c(p, z, MMM_K(mmm_t_sin, 4, MMM_S3)); p = mmm_fma_c(p, z, MMM_K(mmm_t_sin, 5, MMM_S2)); p = mmm_fma_c(p, z, MMM_K(mmm_t_sin, 6, MMM_S1));
   return fma(r * z, p, r);
 }
 MMM_FN double mmm_kcos(double r) {
   double z = r * r;
-  double q = MMM_C8;
-  q = mmm_fma_c(q, z, MMM_C7); q = mmm_fma_c(q, z, MMM_C6); q = mmm_fma_c(q, z, MMM_C5);
-  q = mmm_fma_c(q, z, MMM_C4); q = mmm_fma_c(q, z, MMM_C3); q = mmm_fma_c(q, z, MMM_C2);
+  double q = MMM_K(mmm_t_cos, 0, MMM_C8);
+  q = mmm_fma_c(q, z, MMM_K(mmm_t_cos, 1, MMM_C7)); q = mmm_fma_c(q, z, MMM_K(mmm_t_cos, 2, MMM_C6)); q = mmm_fma_c(q, z, MMM_K(mmm_t_cos, 3, MMM_C5));
+  q = mmm_fma_c(q, z, MMM_K(mmm_t_cos, 4, MMM_C4)); q = mmm_fma_c(q, z, MMM_K(mmm_t_cos, 5, MMM_C3)); q = mmm_fma_c(q, z, MMM_K(mmm_t_cos, 6, MMM_C2));
   return fma(z * z, q, fma(-0.5, z, 1.0));
 }
 /* Cody-Waite reduction by pi/2 (two-part constant: exact for |k| < 2^19) */
@@ -161,10 +176,10 @@ MMM_FN double mmm_atan_ratio(double num, double den, double *lo_out) {
   double c = 0.25 * (double)j;
   double t = (num - c * den) / (den + c * num); /* j == 0: num / den */
   double z = t * t;
-  double p = MMM_A10;
-  p = mmm_fma_c(p, z, MMM_A9); p = mmm_fma_c(p, z, MMM_A8); p = mmm_fma_c(p, z, MMM_A7); p = mmm_fma_c(p, z, MMM_A6);
-  p = mmm_fma_c(p, z, MMM_A5); p = mmm_fma_c(p, z, MMM_A4); p = mmm_fma_c(p, z, MMM_A3); p = mmm_fma_c(p, z, MMM_A2);
-  p = mmm_fma_c(p, z, MMM_A1);
+  double p = MMM_K(mmm_t_atan, 0, MMM_A10);
+  p = mmm_fma_c(p, z, MMM_K(mmm_t_atan, 1, MMM_A9)); p = mmm_fma_c(p, z, MMM_K(mmm_t_atan, 2, MMM_A8)); p = mmm_fma_c(p, z, MMM_K(mmm_t_atan, 3, MMM_A7)); p = mmm_fma_c(p, z, MMM_K(mmm_t_atan, 4, MMM_A6));
+  p = mmm_fma_c(p, z, MMM_K(mmm_t_atan, 5, MMM_A5)); p = mmm_fma_c(p, z, MMM_K(mmm_t_atan, 6, MMM_A4)); p = mmm_fma_c(p, z, MMM_K(mmm_t_atan, 7, MMM_A3)); p = mmm_fma_c(p, z, MMM_K(mmm_t_atan, 8, MMM_A2));
+  p = mmm_fma_c(p, z, MMM_K(mmm_t_atan, 9, MMM_A1));
   double pt = fma(t * z, p, t);
   double hi = j == 0 ? 0.0 : (j == 1 ? MMM_ATAN_HI_1 : (j == 2 ? MMM_ATAN_HI_2 : (j == 3 ? MMM_ATAN_HI_3 : MMM_ATAN_HI_4)));
   double lo = j == 0 ? 0.0 : (j == 1 ? MMM_ATAN_LO_1 : (j == 2 ? MMM_ATAN_LO_2 : (j == 3 ? MMM_ATAN_LO_3 : MMM_ATAN_LO_4)));
@@ -199,10 +214,10 @@ MMM_FN double mmm_exp(double x) {
   double k = rint(x * MMM_INV_LN2);
   double r = fma(-k, MMM_LN2_HI, x);
   r = fma(-k, MMM_LN2_LO, r);
-  double p = MMM_E14;
-  p = mmm_fma_c(p, r, MMM_E13); p = mmm_fma_c(p, r, MMM_E12); p = mmm_fma_c(p, r, MMM_E11); p = mmm_fma_c(p, r, MMM_E10);
-  p = mmm_fma_c(p, r, MMM_E9); p = mmm_fma_c(p, r, MMM_E8); p = mmm_fma_c(p, r, MMM_E7); p = mmm_fma_c(p, r, MMM_E6);
-  p = mmm_fma_c(p, r, MMM_E5); p = mmm_fma_c(p, r, MMM_E4); p = mmm_fma_c(p, r, MMM_E3); p = mmm_fma_c(p, r, MMM_E2);
+  double p = MMM_K(mmm_t_exp, 0, MMM_E14);
+  p = mmm_fma_c(p, r, MMM_K(mmm_t_exp, 1, MMM_E13)); p = mmm_fma_c(p, r, MMM_K(mmm_t_exp, 2, MMM_E12)); p = mmm_fma_c(p, r, MMM_K(mmm_t_exp, 3, MMM_E11)); p = mmm_fma_c(p, r, MMM_K(mmm_t_exp, 4, MMM_E10));
+  p = mmm_fma_c(p, r, MMM_K(mmm_t_exp, 5, MMM_E9)); p = mmm_fma_c(p, r, MMM_K(mmm_t_exp, 6, MMM_E8)); p = mmm_fma_c(p, r, MMM_K(mmm_t_exp, 7, MMM_E7)); p = mmm_fma_c(p, r, MMM_K(mmm_t_exp, 8, MMM_E6));
+  p = mmm_fma_c(p, r, MMM_K(mmm_t_exp, 9, MMM_E5)); p = mmm_fma_c(p, r, MMM_K(mmm_t_exp, 10, MMM_E4)); p = mmm_fma_c(p, r, MMM_K(mmm_t_exp, 11, MMM_E3)); p = mmm_fma_c(p, r, MMM_K(mmm_t_exp, 12, MMM_E2));
   p = fma(p, r * r, r) + 1.0; /* 1 + r + r^2 (1/2 + ...) */
   return ldexp(p, (int)k);
 }
@@ -214,10 +229,10 @@ MMM_FN double mmm_log(double x) {
   double f = m - 1.0;
   double s = f / (2.0 + f);
   double z = s * s;
-  double p = MMM_L11;
-  p = mmm_fma_c(p, z, MMM_L10); p = mmm_fma_c(p, z, MMM_L9); p = mmm_fma_c(p, z, MMM_L8); p = mmm_fma_c(p, z, MMM_L7);
-  p = mmm_fma_c(p, z, MMM_L6); p = mmm_fma_c(p, z, MMM_L5); p = mmm_fma_c(p, z, MMM_L4); p = mmm_fma_c(p, z, MMM_L3);
-  p = mmm_fma_c(p, z, MMM_L2); p = mmm_fma_c(p, z, MMM_L1);
+  double p = MMM_K(mmm_t_log, 0, MMM_L11);
+  p = mmm_fma_c(p, z, MMM_K(mmm_t_log, 1, MMM_L10)); p = mmm_fma_c(p, z, MMM_K(mmm_t_log, 2, MMM_L9)); p = mmm_fma_c(p, z, MMM_K(mmm_t_log, 3, MMM_L8)); p = mmm_fma_c(p, z, MMM_K(mmm_t_log, 4, MMM_L7));
+  p = mmm_fma_c(p, z, MMM_K(mmm_t_log, 5, MMM_L6)); p = mmm_fma_c(p, z, MMM_K(mmm_t_log, 6, MMM_L5)); p = mmm_fma_c(p, z, MMM_K(mmm_t_log, 7, MMM_L4)); p = mmm_fma_c(p, z, MMM_K(mmm_t_log, 8, MMM_L3));
+  p = mmm_fma_c(p, z, MMM_K(mmm_t_log, 9, MMM_L2)); p = mmm_fma_c(p, z, MMM_K(mmm_t_log, 10, MMM_L1));
   double l = 2.0 * fma(s * z, p, s);
   double de = (double)e;
   return fma(de, MMM_LN2_HI, l + de * MMM_LN2_LO);

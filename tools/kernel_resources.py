@@ -3,7 +3,7 @@
 
     python tools/kernel_resources.py [--match step_kernel] [--isa] [objects ...]
 
-Default objects: marl-mass_amd/csrc/mm_main.o mm_general.o mm_ipm.o.  Unbundles the gfx950 code object from the
+Default objects: the seven translation units of marl-mass_amd/csrc (mm_main.o .. mm_split_general.o).  Unbundles the gfx950 code object from the
 .hip_fatbin section (llvm-objcopy + clang-offload-bundler), reads the AMDGPU metadata notes (llvm-readelf) and, with
 --isa, counts instruction classes in the disassembly (llvm-objdump).  Build-container tool: no GPU needed.
 """
@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--isa", action="store_true")
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
-    objs = args.objects or [os.path.join(REPO, "marl-mass_amd", "csrc", n) for n in ("mm_main.o", "mm_general.o", "mm_ipm.o")]
+    objs = args.objects or [os.path.join(REPO, "marl-mass_amd", "csrc", n) for n in ("mm_main.o", "mm_general.o", "mm_ipm.o", "mm_lanes.o", "mm_lanes_ipm.o", "mm_split.o", "mm_split_general.o")]
     rows = []
     with tempfile.TemporaryDirectory() as td:
         for obj in objs:
