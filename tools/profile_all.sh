@@ -9,6 +9,8 @@ declare -A ARGS=(
   [ipm]="--qp-solver ipm"
   [hss_ipm]="--qp-solver ipm --shield hss"
   [mixed44]="--hdv 4"
+  [mixed44_ipm]="--hdv 4 --qp-solver ipm"
+  [density3_ipm]="--traffic-density 3 --agents 11 --qp-solver ipm"
   [g16]="--envs 32768 --agents 12 --pow2-groups"
   [lanes12]="--envs 32768 --agents 12"
   [density3]="--traffic-density 3 --agents 11"
@@ -16,9 +18,9 @@ declare -A ARGS=(
   [density3mixed]="--traffic-density 3 --agents 11 --mixed-traffic"
   [small8192]="--envs 8192"
 )
-TAGS=("$@"); [ ${#TAGS[@]} -gt 0 ] || TAGS=(headline ipm mixed44 lanes12 density1 density3 density3mixed g16 small8192)
+TAGS=("$@"); [ ${#TAGS[@]} -gt 0 ] || TAGS=(headline ipm hss_ipm mixed44 mixed44_ipm lanes12 density1 density3 density3_ipm density3mixed g16 small8192)
 for t in "${TAGS[@]}"; do
-  steps=200; case "$t" in ipm|hss_ipm) steps=30;; esac
+  steps=200; case "$t" in *ipm) steps=30;; esac
   echo "== profile $t: bench.py ${ARGS[$t]}"
   PROF_TAG=$t PROF_STEPS=$steps bash "$R/tools/profile.sh" ${ARGS[$t]} | tail -3
 done
