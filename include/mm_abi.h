@@ -129,7 +129,7 @@ typedef struct MMConfig {
                                    every ego itself); bit1: step in power-of-two lane groups only (no 6- / 12-lane layout for
                                    N = 5..6 / 9..12); bit2: interior-point mode in the fused kernel at any batch size; bit3: in the split
                                    step (phase kernels + lane-per-env sweep kernel) at any batch size -- by default the split step runs
-                                   for CAV-only batches above two fused waves per SIMD.  Validation / A-B timing: same results either way */
+                                   for batches above one fused wave per SIMD (two for N <= 4).  Validation / A-B timing: same results either way */
   double collision_reward;      /* COLLISION_REWARD 200 */
   double high_speed_reward;     /* HIGH_SPEED_REWARD 1  */
   double headway_cost;          /* HEADWAY_COST 4       */

@@ -1434,6 +1434,11 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
 #ifndef MM_IPM_CAV_WAVES
 #define MM_IPM_CAV_WAVES 2
 #endif
+// ... and in groups of 6 lanes and more only up to ONE (steps_split): one wave per SIMD = 512 registers, 6 spilled VGPRs instead
+// of 287 in <8,1,2,false,true,false> (8 192 x 8 MASS: 1.117 -> 1.067 ms per step)
+#ifndef MM_IPM_WIDE_WAVES
+#define MM_IPM_WIDE_WAVES 1
+#endif
 #ifndef MM_SPLIT_WAVES
 #define MM_SPLIT_WAVES 2  // phase form of the step kernel (split interior-point step): 168 registers (3 waves) spill 85 of them
 #endif
@@ -1441,7 +1446,7 @@ template <int G, int SHIELD, bool MIXED>
 #ifndef MM_GENERAL_NONE_WAVES
 #define MM_GENERAL_NONE_WAVES 3  // mixed-traffic unshielded: 0.49 (2 waves) / 0.445 (3) / 0.51 ms (4)
 #endif
-constexpr int step_min_waves(bool ipm = false) { return SHIELD == MM_SHIELD_NONE ? (G >= MM_NONE_WIDE_G ? 2 : (MIXED ? MM_GENERAL_NONE_WAVES : MM_NONE_WAVES)) : (ipm ? (MIXED ? MM_IPM_WAVES : MM_IPM_CAV_WAVES) : MM_MIN_WAVES); }
+constexpr int step_min_waves(bool ipm = false) { return SHIELD == MM_SHIELD_NONE ? (G >= MM_NONE_WIDE_G ? 2 : (MIXED ? MM_GENERAL_NONE_WAVES : MM_NONE_WAVES)) : (ipm ? (G >= 6 ? MM_IPM_WIDE_WAVES : (MIXED ? MM_IPM_WAVES : MM_IPM_CAV_WAVES)) : MM_MIN_WAVES); }
 // IPM: the MM_QP_IPM fidelity mode (the shield's QP by cvxopt's interior-point algorithm, include/mm_qp.h); carried by
 // general (MIXED) instantiations only, which run the literal sweep -- one QP per vehicle per sub-step, as the reference
 // TRACE: the per-sub-step trace planes (MMStepOut.trace, tests / profile export) are a compile-time property: the
@@ -2814,16 +2819,17 @@ static bool needs_general(const MMHandle_ *h) {  // HDVs can appear, or steer_ve
 // The interior-point mode of a CAV-only shielded batch steps as phase kernels + sweep kernels (SweepBuf above) once the
 // batch is large enough for it.  The split step takes as long as its slowest env needs for its QP chain, almost independent of
 // the batch (one lane per env, one wave per SIMD up to 65 536 envs); the fused kernel iterates with ~8 of 64 lanes busy but a
-// small batch leaves the chip's other lanes idle anyway.  Measured at N = 8 MASS (ms per step, fused / split): 8 192 envs
-// 1.12 / 1.45, 16 384 envs 1.46 / 1.53, 32 768 envs 2.49 / 1.72, 65 536 envs 4.4 / 1.99; 4 096 x 4 HSS 0.30 / 0.61.  Crossover =
-// more than two fused waves per SIMD.  debug_flags bit2 keeps the fused kernel, bit3 forces the split step at any size
+// small batch leaves the chip's other lanes idle anyway.  Measured at N = 8 MASS (ms per step, fused / split; tools/split_crossover.sh):
+// 8 192 envs 1.12 / 1.31, 12 288 envs 1.43 / 1.33, 16 384 envs 1.46 / 1.36, 32 768 envs 2.46 / 1.54; N = 4 HSS: 4 096 envs 0.30 /
+// 0.64, 16 384 envs 0.32 / 0.73.  Crossover = more than one fused wave per SIMD for the 8- and 16-lane groups (long chains per
+// env), more than two for the 2- and 4-lane groups.  debug_flags bit2 keeps the fused kernel, bit3 forces the split step at any size
 // (validation / A-B timing: same results either way).
 static bool steps_split(const MMHandle_ *h) {
   if (!(h->cfg.env_kind == MM_ENV_V1 && h->cfg.shield != MM_SHIELD_NONE && h->cfg.qp_solver == MM_QP_IPM)) return false;
   if (h->cfg.debug_flags & 4) return false;
   if (h->cfg.debug_flags & 8) return true;
   const int g = h->N <= 2 ? 2 : (h->N <= 4 ? 4 : (h->N <= 8 ? 8 : 16));
-  return (long long)h->E * g / 64 > 2ll * (h->n_simd > 0 ? h->n_simd : 1024);
+  return (long long)h->E * g / 64 > (g >= 8 ? 1ll : 2ll) * (h->n_simd > 0 ? h->n_simd : 1024);
 }
 
 // waves one step launch starts (launch_step_t rounds the grid up to whole MM_STEP_BLOCK-thread blocks): every one of them
