@@ -190,6 +190,10 @@ MM_DEV void for_partners(F f) { for_partners_impl<1, G>(f); }
 // prepared for a specific reader, so the two pairings are interchangeable (the one message-style exchange, the 16-lane
 // classification, is not compiled for the rotation layouts: they use the LDS mailbox like the 8-lane groups).
 template <int G> constexpr bool kPow2 = (G & (G - 1)) == 0;
+#ifndef MM_ROUNDS_LITE
+#define MM_ROUNDS_LITE 1
+#endif
+constexpr bool kRoundsLite = MM_ROUNDS_LITE != 0;  // exact-mode MASS rounds: acceleration only, shield_post once (see the rounds)
 template <int M, int G>
 MM_DEV int pidx(int a) {  // creation index of partner M of the vehicle with index a
   if constexpr (kPow2<G>) return a ^ M;
@@ -2018,6 +2022,31 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
             }
             if (shield_on) so = shield_post<MASS>(c, v, ss, shield_rows<true>(c, ss, nb), qc_d, (qc_meta & 8) != 0, true);
           } else {
+          if constexpr (MASS && kRoundsLite) {
+            // The rounds need the decided ACCELERATION only: rows, the QP and derived_acceleration.  Status, is_lc_allowed, veto and
+            // flags (shield_post) are evaluated once, on the rows the fixed point ended with -- except for a lane in the slow-LC
+            // bypass (decentral_layer.py:746-750), whose acceleration depends on its veto.
+            const bool slow_lc = (v.hl == 2 || v.hl == 0) && v.v < kStoppingSpeed;
+            ShieldRows rr;
+            double d_cur = 0.0;
+            for (int round = 0; round <= st.N; round++) {
+              const double gu_cur = slot_gu<true>(h1vx_mine, acc_cur, mine_gvx, dt);  // my post-step record under my current decision
+              const double da = shfl_d(gu_cur, src_ol), db = shfl_d(gu_cur, src_oa);
+              if (ol_dyn) nb.ol_gu = da;
+              if (oa_dyn) nb.oa_gu = db;
+              rr = shield_rows<true>(c, ss, nb);
+              d_cur = qp_exact(ss, rr);
+              double acc_next = v.act_acc;
+              if (shield_on) {
+                if (slow_lc) acc_next = shield_post<true>(c, v, ss, rr, d_cur, true, false).acc;
+                else acc_next = div_c((ss.u0 + d_cur) - ss.evx, dt, c.inv_dt);  // derived_acceleration :80-82 (shield_post's expression)
+              }
+              const bool changed = __double_as_longlong(acc_next) != __double_as_longlong(acc_cur);
+              acc_cur = acc_next;
+              if (!__any(changed)) break;  // (an exit test on "a decision some lane READS changed" saves a round and still measured 3 % slower)
+            }
+            so = shield_post<true>(c, v, ss, rr, d_cur, true, false);
+          } else {
           for (int round = 0; round <= st.N; round++) {
             if (MASS) {
               const double gu_cur = slot_gu<true>(h1vx_mine, acc_cur, mine_gvx, dt);  // my post-step record under my current decision
@@ -2030,6 +2059,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
             const bool changed = __double_as_longlong(acc_next) != __double_as_longlong(acc_cur);
             acc_cur = acc_next;
             if (!MASS || !__any(changed)) break;
+          }
           }
           }
           if (TRACE && shield_on) trace_status(out.trace + (long long)k * MM_T_COUNT * A + i, A, so);
