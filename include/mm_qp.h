@@ -226,7 +226,8 @@ MMM_FN int mm_qp_row_state(double s, double z, double rz, double hmag) {  /* 1 a
   return 0;
 }
 MMM_FN int mm_qp_frozen(const MMQpState *q, const MMQpRes *r) {
-  if (q->iters < 8 || !(q->a > 0.0)) return 0;
+  if (q->iters < 16 || !(q->a > 0.0)) return 0;  /* (never met earlier: first at 17 in 1.5e8 capped QPs, tools/qp_certificate_fuzz.c; a QP that
+                                                     converges is through by iteration 11 and should not pay for the conditions below) */
   if (!(fabs(q->ax0) <= 0x1p-75 * fabs(q->x0)) || !(fabs(q->ax2) <= 0x1p-75 * fabs(q->x2))) return 0;             /* (1) */
   if (q->x0 != -q->h2 || mm_qp_row_state(q->s2, q->z2, r->rz2, fabs(q->h2)) != 1 || !(q->z1 <= 0x1p-60)) return 0; /* (2) */
   const int r0 = mm_qp_row_state(q->s0, q->z0, r->rz0, fmax(fabs(q->h0), fabs(q->x2)));
