@@ -193,7 +193,11 @@ template <int G> constexpr bool kPow2 = (G & (G - 1)) == 0;
 #ifndef MM_ROUNDS_LITE
 #define MM_ROUNDS_LITE 1
 #endif
-constexpr bool kRoundsLite = MM_ROUNDS_LITE != 0;  // exact-mode MASS rounds: acceleration only, shield_post once (see the rounds)
+constexpr bool kRoundsLite = MM_ROUNDS_LITE != 0;
+#ifndef MM_VETO_PRIOR
+#define MM_VETO_PRIOR 1
+#endif
+constexpr bool kVetoPrior = MM_VETO_PRIOR != 0;  // parallel form: the previous sub-step's veto as the first guess of the veto passes  // exact-mode MASS rounds: acceleration only, shield_post once (see the rounds)
 template <int M, int G>
 MM_DEV int pidx(int a) {  // creation index of partner M of the vehicle with index a
   if constexpr (kPow2<G>) return a ^ M;
@@ -1771,6 +1775,13 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
     double new_acc = v.act_acc;
     bool use_B = false, veto = false;
     int new_flags = v.flags;
+    if constexpr (SHIELDED && !SPLIT && !kSerialOnly && kVetoPrior) {
+      // First guess of the veto passes below: what this vehicle's shield said one sub-step ago (a vetoed lane change usually
+      // stays vetoed: starting from "no veto" cost such a wave a second classification + solve pass in every sub-step).  The
+      // passes converge to the sequential answer from ANY first guess (rank r is final after pass r); a wrong one costs
+      // the pass the right one saves.
+      if ((c.debug_flags & 1) == 0 && shield_on && needB && !(v.flags & MM_FLAG_IS_LC_SAFE)) { make_B(); use_B = true; }
+    }
     if constexpr (SPLIT) {
       if (head) {
         // act half of sub-step k: hand the shield's inputs to the sweep kernel (one lane per env there)
