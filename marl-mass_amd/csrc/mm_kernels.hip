@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
   // (16-bit planes: with NV = 11 the wave's LDS stays under 40 KB = four single-wave workgroups per CU, one per SIMD)
   __shared__ unsigned short s_pk[NV][64], s_meta[NV][64], s_cls[NV][64];
   // SW_META packed into 9 bits: live | shield_on | needB | Vehicle flags (3 bits) << 3 | hl_action (0..4, 7 = None) << 6
-  auto pack_meta = [](int m) { const int hl = (m >> 16) & 255; return (unsigned short)((m & 7) | ((m >> 8) & 7) << 3 | (hl > 4 ? 7 : hl) << 6 | ((m >> 3) & 1) << 9); };  // (bit 9: HDV)
+  auto pack_meta = [](int m) { const int hl = (m >> 16) & 255; return (unsigned short)((m & 7) | ((m >> 8) & 7) << 3 | (hl > 4 ? 7 : hl) << 6 | ((m >> 3) & 1) << 9 | ((m >> 4) & 1) << 10); };  // (bit 9: HDV, bit 10: the candidate the phase kernel's slot selection assumed is B)
   enum { PH_SETUP = 0, PH_RUN = 1, PH_FIN = 2, PH_DONE = 3 };
   int phase = e < c.E ? PH_SETUP : PH_DONE;
   unsigned long long ord_lo = ~0ull, ord_hi = ~0ull;  // sweep order, one byte per rank (0..7 | 8..15)
@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(64, 1) void sweep_kernel(DevCfg c, DevState st, Swe
           t[MM_T_QP_H0 * A] = so.qt.h0; t[MM_T_QP_H1 * A] = so.qt.h1; t[MM_T_QP_H2 * A] = so.qt.h2;
           t[MM_T_QP_H3 * A] = so.qt.h3; t[MM_T_QP_D * A] = so.qt.d; t[MM_T_LC_MARGIN * A] = so.qt.margin;
         }
-        dirty = dirty || use_B;
+        dirty = dirty || use_B != (((ego_meta >> 10) & 1) != 0);  // committed the other candidate than the phase kernel's slot selection assumed
         r += 1;
         phase = PH_SETUP;
       }
@@ -1786,9 +1786,12 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
       if (head) {
         // act half of sub-step k: hand the shield's inputs to the sweep kernel (one lane per env there)
         make_B();  // (eagerly, like the literal sweep: the sweep kernel decides the vetoes)
+        // the classification pass below assumes every vehicle commits the candidate its LAST veto decision points to (bit 4 of
+        // SW_META); the sweep kernel classifies an env itself only from the first vehicle on that decides otherwise
+        if constexpr (!kSerialOnly && kVetoPrior) use_B = (c.debug_flags & 1) == 0 && shield_on && needB && !(v.flags & MM_FLAG_IS_LC_SAFE);
         const int n_live = __popc(group_ballot<G>(live, gb));
         if (valid) {
-          sw_i(sb, SW_META, a, e) = (live ? 1 : 0) | (shield_on ? 2 : 0) | (needB ? 4 : 0) | (hdv ? 8 : 0) | (v.flags & 255) << 8 | (v.hl & 255) << 16;
+          sw_i(sb, SW_META, a, e) = (live ? 1 : 0) | (shield_on ? 2 : 0) | (needB ? 4 : 0) | (hdv ? 8 : 0) | (use_B ? 16 : 0) | (v.flags & 255) << 8 | (v.hl & 255) << 16;
           if (live) {
             // (the pre-step view the literal sweep starts from -- serial form below: wx .. wgu -- is built by the sweep kernel from
             // the state planes this launch stores; only what is not state goes through the hand-off planes)
