@@ -1850,6 +1850,9 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
         int qc_meta = 0;  // rows (3 | 4; 0: nothing cached) | 8: status "optimal"
         (void)qc_h0; (void)qc_h3; (void)qc_d; (void)qc_meta;
         for (int pass = 0; pass <= st.N; pass++) {
+#ifdef MM_STAMPS
+          if ((threadIdx.x & 63) == 13) _t_acc += 1 + (pass == 0 ? 1ull << 32 : 0ull);  // (stamps builds: veto passes | wave-sub-steps << 32)
+#endif
           const double mine_gvx = s_cold[(use_B ? C_B : C_A) + 6][tid];  // g.vx of the candidate I commit
           const double h1vx_mine = s_cold[C_H1VX][tid];
           s_cold[C_GU0][tid] = slot_gu<MASS>(s_cold[C_H2VX][tid], MASS ? s_cold[C_SACC][tid] : kCbfAccLo, GVX(), dt);
@@ -2086,9 +2089,6 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
           if (!__any(flip)) break;
         }
         serial = __any(irregular);
-#ifdef MM_STAMPS
-        if ((threadIdx.x & 63) == 13) _t_acc += 1;
-#endif
         if (!serial && shield_on) {
           new_acc = so.acc; veto = so.veto; new_flags = so.flags; qt = so.qt;
           if (IPM && so.bounds) atomicOr(c.err, MM_LATCH_QP_BOUNDS);  // check_bounds on the QP this vehicle finally solved

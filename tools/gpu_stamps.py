@@ -2,7 +2,7 @@
 import ctypes, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-os.environ["MM_HIP_LIB"] = os.path.join(REPO, "marl-mass_amd", "csrc", "libmm_hip_stamps.so")
+os.environ.setdefault("MM_HIP_LIB", os.path.join(REPO, "marl-mass_amd", "csrc", "libmm_hip_stamps.so"))
 import torch
 from marl_mass_amd import VecMergeEnv, hip_library
 shield = sys.argv[1] if len(sys.argv) > 1 else "cbf-cav"
@@ -36,7 +36,8 @@ out = {"workload": "%d envs x 8 CAVs, %s, stationary batch (staggered phases + 1
        "build": "-DMM_STAMPS -DMM_ONLY_G=8 -DMM_ONLY_MIXED=false (s_memtime stamps cost ~10 %% themselves)",
        "cycles_per_wave_step": {n: buf[k] / waves / K for k, n in enumerate(names) if k != 13}, "total_cycles_per_wave_step": tot / waves / K,
        "share": {n: buf[k] / tot for k, n in enumerate(names) if k != 13},
-       "shielded_wave_substeps": int(buf[13])}
+       "shielded_wave_substeps": int(buf[13]) >> 32, "veto_passes": int(buf[13]) & 0xFFFFFFFF,
+       "veto_passes_per_wave_substep": (int(buf[13]) & 0xFFFFFFFF) / max(int(buf[13]) >> 32, 1)}
 os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(REPO, "gpurun_out", "phase_cycles_%s%s%s.json" % (shield, "_hdv%d" % n_hdv if n_hdv else "", "" if E == 65536 else "_E%d" % E)), "w"), indent=1)
-print("shielded wave-sub-steps %d" % buf[13])
+print("shielded wave-sub-steps %d, veto passes per wave-sub-step %.3f" % (int(buf[13]) >> 32, (int(buf[13]) & 0xFFFFFFFF) / max(int(buf[13]) >> 32, 1)))
