@@ -214,6 +214,42 @@ def test_parallel_sweep_equals_literal_serial_sweep(safety, N):
         assert torch.equal(fast.obs, slow.obs) and torch.equal(fast.out["reward"], slow.out["reward"]), t
 
 
+@pytest.mark.parametrize("qp,debug_flags,E", [("exact", 0, 1024), ("ipm", 4, 160), ("ipm", 8, 160)], ids=["exact", "ipm-fused", "ipm-split"])
+@pytest.mark.parametrize("safety", ["cbf-cav", "cbf-avs_cint"])
+def test_veto_passes_converge_from_any_first_guess(safety, qp, debug_flags, E):
+    """The parallel form's veto passes (and the split step's slot selection) start from the veto each vehicle's shield decided
+    one sub-step ago -- the `is_lc_safe` flag of the state -- as a FIRST GUESS.  The passes converge to the sequential answer
+    from any guess: the same batch stepped from the same state with that flag bit scrambled gives identical bits everywhere
+    (every present vehicle's flags are rewritten by the step's third sub-step at the latest; the default reward reads none)."""
+    N = 8
+    kw = dict(env_id="merge-multi-agent-v1", config={"safety_guarantee": safety, "HEADWAY_TIME": 0.5}, cbf_eta=0.03125,
+              qp_solver=qp, cbf_tau=0.5, seed=777, auto_reset=True, trace=True, debug_flags=debug_flags)
+    a, b = _gpu_env(E, N, **kw), _gpu_env(E, N, **kw)
+    a.reset()
+    b.reset()
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    p = torch.tensor([0.3, 0.2, 0.3, 0.1, 0.1], device="cuda:0")
+    flipped = 0
+    for t in range(60):
+        act = torch.multinomial(p, E * N, True, generator=g).view(E, N).int()
+        b.state.copy_(a.state)
+        flip = (torch.rand(b.u8[abi.B["KIND"]].shape, device="cuda:0", generator=g) < 0.5) & (b.u8[abi.B["KIND"]] != 0)
+        b.u8[abi.B["FLAGS"]] ^= flip.to(torch.uint8) * abi.FLAG_IS_LC_SAFE
+        flipped += int(flip.sum())
+        a.step(act)
+        b.step(act)
+        assert torch.equal(a.u8, b.u8), t
+        assert torch.equal(a.f64.nan_to_num(), b.f64.nan_to_num()), t
+        assert torch.equal(a.env_i32, b.env_i32), t
+        # (the trace's FLAGS plane shows the scrambled bit itself in the sub-steps before a new vehicle's first shield call)
+        keep = [i for i, n in enumerate(abi.T_PLANES) if n != "FLAGS"]
+        assert torch.equal(a.trace[:, keep].nan_to_num(), b.trace[:, keep].nan_to_num()), t
+        assert torch.equal(a.obs, b.obs) and torch.equal(a.out["reward"], b.out["reward"]), t
+    assert flipped > E * N * 10
+    a.poll_errors()
+    b.poll_errors()
+
+
 @pytest.mark.parametrize("env_id,safety,N,E,n_hdv,lateral", [
     ("merge-multi-agent-v1", "cbf-cav", 6, 333, 0, "steer"), ("merge-multi-agent-v1", "cbf-cav", 11, 37, 0, "steer"),
     ("merge-multi-agent-v1", "cbf-cav", 12, 256, 0, "steer"), ("merge-multi-agent-v1", "cbf-avs_cint", 5, 1, 0, "steer"),
