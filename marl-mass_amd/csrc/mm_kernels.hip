@@ -197,10 +197,6 @@ constexpr bool kRoundsLite = MM_ROUNDS_LITE != 0;
 #ifndef MM_VETO_PRIOR
 #define MM_VETO_PRIOR 1
 #endif
-#ifndef MM_EAGER_STEER_B
-#define MM_EAGER_STEER_B 0
-#endif
-constexpr bool kEagerSteerB = MM_EAGER_STEER_B != 0;  // experiment: B's steering_control in the act block (two independent chains)
 constexpr bool kVetoPrior = MM_VETO_PRIOR != 0;  // parallel form: the previous sub-step's veto as the first guess of the veto passes  // exact-mode MASS rounds: acceleration only, shield_post once (see the rounds)
 template <int M, int G>
 MM_DEV int pidx(int a) {  // creation index of partner M of the vehicle with index a
@@ -1600,12 +1596,7 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
       if (time % c.nsub == 0) hl_act<KIND>(v, action);  // action_type.act abstract.py:516-519
     }
     const int tl_pre = v.tlane;  // what an HDV acting before this vehicle still sees
-    double steerB_pre = 0.0, tB_pre = 0.0;  // (kEagerSteerB) candidate B's steering command, evaluated beside A's
-    (void)steerB_pre; (void)tB_pre;
-    if (live && !hdv && head) {
-      controlled_act<!MIXED>(v, -1, sv, st_t);  // road.act road.py:269-278 (general kernels: steering below)
-      if constexpr (SHIELDED && !MIXED && kEagerSteerB) steerB_pre = steering_control(v.x, v.y, v.h, v.v, v.lane, tB_pre);
-    }
+    if (live && !hdv && head) controlled_act<!MIXED>(v, -1, sv, st_t);  // road.act road.py:269-278 (general kernels: steering below)
     if (head) s_cold[C_TSPEED][tid] = v.tspeed;
     if constexpr (MIXED) { STAMP(1); }  // (general kernels: "act" = the CAVs' part up to here; slots 3 / 4 / 5 split the HDVs' part)
     if constexpr (MIXED) {
@@ -1739,9 +1730,8 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
     auto make_B = [&]() {
       if constexpr (SHIELDED) {
         if (needB && !haveB) {
-          double tB, steerB;
-          if constexpr (!MIXED && kEagerSteerB) { steerB = steerB_pre; tB = tB_pre; }
-          else steerB = steering_control(v.x, v.y, v.h, v.v, v.lane, tB);
+          double tB;
+          double steerB = steering_control(v.x, v.y, v.h, v.v, v.lane, tB);
           if (sv) steerB = steer_vel_command(steerB, v.sang);
           park(std::integral_constant<int, C_B>{}, predict<KIND, true, MASS, MIXED>(v, steerB, tB, spsi, CPSI(), dt, sv), steerB);
           haveB = true;
