@@ -90,7 +90,8 @@ enum {
 #define MM_LATERAL_STEER 0
 #define MM_LATERAL_STEER_VEL 1
 #define MM_FLAG_COLLABORATE_ADJ 1u
-#define MM_FLAG_IS_LC_SAFE 2u
+#define MM_FLAG_IS_LC_SAFE 2u  /* vehicle.is_lc_safe of the last shield call (decentral_layer.py:504,742).  The HIP step also reads it as the FIRST GUESS of
+                                  this sub-step's veto (a scheduling prior: results do not depend on it, tests/test_hip_parity.py) */
 #define MM_FLAG_IS_COLLABORATING 4u
 #define MM_HL_NONE 255u
 
