@@ -1851,7 +1851,11 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
         (void)qc_h0; (void)qc_h3; (void)qc_d; (void)qc_meta;
         for (int pass = 0; pass <= st.N; pass++) {
 #ifdef MM_STAMPS
+#ifdef MM_COUNT_ROUNDS  // (one-off: count the MASS rounds instead of the passes)
+          if ((threadIdx.x & 63) == 13) _t_acc += (pass == 0 ? 1ull << 32 : 0ull);
+#else
           if ((threadIdx.x & 63) == 13) _t_acc += 1 + (pass == 0 ? 1ull << 32 : 0ull);  // (stamps builds: veto passes | wave-sub-steps << 32)
+#endif
 #endif
           const double mine_gvx = s_cold[(use_B ? C_B : C_A) + 6][tid];  // g.vx of the candidate I commit
           const double h1vx_mine = s_cold[C_H1VX][tid];
@@ -2047,6 +2051,9 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
             ShieldRows rr;
             double d_cur = 0.0;
             for (int round = 0; round <= st.N; round++) {
+#if defined(MM_STAMPS) && defined(MM_COUNT_ROUNDS)
+              if ((threadIdx.x & 63) == 13) _t_acc += 1;
+#endif
               const double gu_cur = slot_gu<true>(h1vx_mine, acc_cur, mine_gvx, dt);  // my post-step record under my current decision
               const double da = shfl_d(gu_cur, src_ol), db = shfl_d(gu_cur, src_oa);
               if (ol_dyn) nb.ol_gu = da;
@@ -2060,7 +2067,10 @@ __global__ __launch_bounds__(MM_STEP_BLOCK, (SPLIT ? MM_SPLIT_WAVES : step_min_w
               }
               const bool changed = __double_as_longlong(acc_next) != __double_as_longlong(acc_cur);
               acc_cur = acc_next;
-              if (!__any(changed)) break;  // (an exit test on "a decision some lane READS changed" saves a round and still measured 3 % slower)
+              // (4.3 rounds per pass on the headline batch.  Leaving without the confirming round -- on "no decision some lane
+              // reads changed", by ballot, or on "no lane received anything new" at the next exchange -- saves an evaluation and
+              // measured 2 - 3 % SLOWER both ways: profiles/r04/variants.jsonl)
+              if (!__any(changed)) break;
             }
             so = shield_post<true>(c, v, ss, rr, d_cur, true, false);
           } else {
